@@ -1,0 +1,327 @@
+// kvarq_amd/csrc/kernels_general.hip -- the exhaustive scan path: fully general
+// (any bytes, any read/sequence length, any config), one kernel per stage of
+// the reference's scan_filepart (workhorse.c:976-1197).  It serves sequences
+// and configs the seed-filter kernel cannot (kernels_seeded.hip), and is the
+// on-device cross-check of that kernel in the tests.
+//
+//   kvq_count_lines    newline count per 4 KiB segment of every chunk          (1018-1030)
+//   kvq_scan_segments  per-chunk exclusive scan of those counts, records/chunk (1033: four '\n' = one record)
+//   kvq_index_records  positions of the four '\n' of every complete record     (1024-1029)
+//   kvq_trim_records   '@'/'+' checks, longest quality run, length histogram   (1037-1070)
+//   kvq_match_all      every read against every listed sequence, classes A/B/C (1107-1175)
+//   kvq_fold_hits      per-sequence counters, coverage/mutation fold, hit bytes (434-439, analyse.py:57-78)
+#include "kvq_device.h"
+
+// ---------------------------------------------------------------------------
+// newline indexing
+// ---------------------------------------------------------------------------
+
+// flags of the newlines among the 16 bytes a lane owns in one round
+struct Lane16 { uint32_t f[4]; uint32_t p; };
+
+__device__ __forceinline__ Lane16 load_lane16(const uint8_t *data, uint32_t p, uint32_t a, uint32_t b)
+{
+    Lane16 r; r.p = p;
+    if (p >= b || p + 16u <= a) { r.f[0] = r.f[1] = r.f[2] = r.f[3] = 0u; return r; }
+    const uint4 v = *reinterpret_cast<const uint4 *>(data + p);      // p is a multiple of 16
+    const uint32_t x[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t f = kvq_nl_flags(x[d]);
+        if (p + 4u * d < a || p + 4u * d + 4u > b) f &= kvq_range_flags(p + 4u * d, a, b);
+        r.f[d] = f;
+    }
+    return r;
+}
+
+// grid (gx, nchunks), 256 threads: wave w of block bx handles segments
+// bx*4+w, bx*4+w+4*gx, ... of chunk blockIdx.y
+extern "C" __global__ void __launch_bounds__(256)
+kvq_count_lines(const uint8_t *__restrict__ data, const uint32_t *__restrict__ chunk_off,
+                const uint32_t *__restrict__ chunk_seg_base, uint32_t *__restrict__ seg_cnt)
+{
+    const uint32_t c = blockIdx.y;
+    const uint32_t a = chunk_off[c], b = chunk_off[c + 1];
+    const uint32_t A = a & ~15u;
+    const uint32_t nseg = chunk_seg_base[c + 1] - chunk_seg_base[c];
+    const int lane = kvq_lane();
+    for (uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6); k < nseg; k += gridDim.x * 4u) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const Lane16 l = load_lane16(data, A + k * KVQ_SEG_BYTES + r * 1024u + lane * 16u, a, b);
+            cnt += __popc(l.f[0]) + __popc(l.f[1]) + __popc(l.f[2]) + __popc(l.f[3]);
+        }
+        cnt = kvq_wave_incl_scan(cnt);
+        if (lane == 63) seg_cnt[chunk_seg_base[c] + k] = cnt;
+    }
+}
+
+// one wave per chunk: exclusive scan of its segment counts (in place), number
+// of complete records of the chunk
+extern "C" __global__ void __launch_bounds__(256)
+kvq_scan_segments(uint32_t nchunks, const uint32_t *__restrict__ chunk_seg_base,
+                  uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ chunk_nrec)
+{
+    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const int lane = kvq_lane();
+    const uint32_t s0 = chunk_seg_base[c], s1 = chunk_seg_base[c + 1];
+    uint32_t run = 0;
+    for (uint32_t s = s0; s < s1; s += 64u) {
+        const uint32_t v = (s + lane < s1) ? seg_cnt[s + lane] : 0u;
+        const uint32_t inc = kvq_wave_incl_scan(v);
+        if (s + lane < s1) seg_cnt[s + lane] = run + inc - v;
+        run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) chunk_nrec[c] = run >> 2;
+}
+
+// same geometry as kvq_count_lines.  nl4[4*g + k] = batch offset of the k-th
+// '\n' of record g; rec_start[g] = batch offset of its first byte
+extern "C" __global__ void __launch_bounds__(256)
+kvq_index_records(const uint8_t *__restrict__ data, const uint32_t *__restrict__ chunk_off,
+                  const uint32_t *__restrict__ chunk_seg_base, const uint32_t *__restrict__ seg_excl,
+                  const uint32_t *__restrict__ chunk_nrec, const uint32_t *__restrict__ chunk_rec_base,
+                  uint32_t *__restrict__ nl4, uint32_t *__restrict__ rec_start)
+{
+    const uint32_t c = blockIdx.y;
+    const uint32_t a = chunk_off[c], b = chunk_off[c + 1];
+    const uint32_t A = a & ~15u;
+    const uint32_t nseg = chunk_seg_base[c + 1] - chunk_seg_base[c];
+    const uint32_t nrec = chunk_nrec[c];
+    const uint32_t limit = nrec * 4u;
+    const uint32_t g0 = chunk_rec_base[c];
+    const int lane = kvq_lane();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nrec > 0) rec_start[g0] = a;
+    for (uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6); k < nseg; k += gridDim.x * 4u) {
+        uint32_t base = seg_excl[chunk_seg_base[c] + k];
+        if (base >= limit) continue;              // only the dropped partial tail lives here
+#pragma unroll 1
+        for (int r = 0; r < 4; r++) {
+            const Lane16 l = load_lane16(data, A + k * KVQ_SEG_BYTES + r * 1024u + lane * 16u, a, b);
+            const uint32_t cnt = __popc(l.f[0]) + __popc(l.f[1]) + __popc(l.f[2]) + __popc(l.f[3]);
+            const uint32_t inc = kvq_wave_incl_scan(cnt);
+            uint32_t n = base + inc - cnt;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                uint32_t f = l.f[d];
+                while (f) {
+                    const int bit = __ffs((int)f) - 1;          // 7, 15, 23 or 31
+                    f &= f - 1u;
+                    const uint32_t pos = l.p + 4u * d + (uint32_t)(bit >> 3);
+                    if (n < limit) {
+                        nl4[(size_t)g0 * 4u + n] = pos;
+                        if ((n & 3u) == 3u && n + 1u < limit) rec_start[g0 + ((n + 1u) >> 2)] = pos + 1u;
+                    }
+                    n++;
+                }
+            }
+            base += __shfl(inc, 63, 64);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// quality trim
+// ---------------------------------------------------------------------------
+
+// running state of the longest-run search over the quality line, fed 64 bits
+// at a time (bit i = score byte >= Amin).  A run only counts when a low byte
+// closes it; the first of equally long runs wins (workhorse.c:1055-1068).
+struct RunState { int in_run; uint32_t run_start; int best; uint32_t best_start; };
+
+__device__ __forceinline__ void run_feed(RunState &st, uint64_t good, int nbits, uint32_t base)
+{
+    int pos = 0;
+    while (pos < nbits) {
+        if (st.in_run) {
+            const uint64_t z = (~good) >> pos;
+            const int d = z ? __ffsll((long long)z) - 1 : 64;
+            if (pos + d >= nbits) break;                       // run continues in the next word
+            const int len = (int)(base + pos + d - st.run_start);
+            if (len > st.best) { st.best = len; st.best_start = st.run_start; }
+            st.in_run = 0;
+            pos += d + 1;
+        } else {
+            const uint64_t o = good >> pos;
+            const int d = o ? __ffsll((long long)o) - 1 : 64;
+            if (pos + d >= nbits) break;
+            st.run_start = base + pos + d;
+            st.in_run = 1;
+            pos += d;
+        }
+    }
+}
+
+#define KVQ_TRIM_RPW 16   // records per wave
+
+// one wave per record, KVQ_TRIM_RPW consecutive records per wave.
+// read_off[g] = batch offset of the first base of the trimmed read,
+// read_len[g] = its length, or -1 when shorter than minreadlength (workhorse.c:1100)
+extern "C" __global__ void __launch_bounds__(256)
+kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, uint32_t nrec,
+                 const uint32_t *__restrict__ nl4, const uint32_t *__restrict__ rec_start,
+                 uint32_t *__restrict__ read_off, int32_t *__restrict__ read_len, int32_t count)
+{
+    __shared__ unsigned int hist[KVQ_RL_BINS];
+    __shared__ int longest;
+    for (int i = threadIdx.x; i < KVQ_RL_BINS; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) longest = -1;
+    __syncthreads();
+
+    const int lane = kvq_lane();
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t g_begin = wave * KVQ_TRIM_RPW;
+    for (uint32_t g = g_begin; g < g_begin + KVQ_TRIM_RPW && g < nrec; g++) {
+        const uint32_t rstart = rec_start[g];
+        const uint32_t n0 = nl4[4 * (size_t)g], n1 = nl4[4 * (size_t)g + 1], n2 = nl4[4 * (size_t)g + 2], n3 = nl4[4 * (size_t)g + 3];
+        const uint32_t sread = n0 + 1u, plus = n1 + 1u, sscore = n2 + 1u;
+        if (lane == 0) {
+            const uint8_t c0 = data[rstart];
+            if (c0 != '@')
+                atomicMin(P.err, ((unsigned long long)(fpos_base + rstart) << 16) | (0ull << 8) | c0);
+            else if (data[plus] != '+')
+                atomicMin(P.err, ((unsigned long long)(fpos_base + plus) << 16) | (1ull << 8) | data[plus]);
+        }
+        // score line including its '\n': bytes [sscore, n3]
+        const uint32_t qlen = n3 - sscore + 1u;
+        RunState st; st.in_run = 1; st.run_start = 0; st.best = 0; st.best_start = 0;   // qtr starts at startscore (1055)
+        for (uint32_t o = 0; o < qlen; o += 64u) {
+            const uint32_t i = o + lane;
+            const bool ok = (i < qlen) && ((int)(int8_t)data[sscore + i] >= P.amin);
+            const uint64_t good = __ballot(ok);
+            const int nbits = (qlen - o) < 64u ? (int)(qlen - o) : 64;
+            run_feed(st, good, nbits, o);
+        }
+        const int rl = st.best;
+        if (lane == 0) {
+            if (count) {
+                if (rl < KVQ_RL_BINS) atomicAdd(&hist[rl], 1u);          // add_rl, 394-402
+                atomicMax(&longest, rl);
+            }
+            read_off[g] = sread + st.best_start;                          // 1070
+            read_len[g] = rl >= P.minreadlength ? rl : -1;
+        }
+    }
+    __syncthreads();
+    if (!count) return;
+    for (int i = threadIdx.x; i < KVQ_RL_BINS; i += blockDim.x)
+        if (hist[i]) atomicAdd(&P.ctr[KVQ_CTR_RL_ + i], (unsigned long long)hist[i]);
+    if (threadIdx.x == 0) {
+        if (longest >= 0) atomicMax(&P.ctr[KVQ_CTR_LONGEST_], (unsigned long long)(longest + 1));
+        // records of this block (add_records_parsed, 1187)
+        const uint32_t first = blockIdx.x * 4u * KVQ_TRIM_RPW;
+        const uint32_t n = nrec > first ? (nrec - first < 4u * KVQ_TRIM_RPW ? nrec - first : 4u * KVQ_TRIM_RPW) : 0u;
+        if (n) atomicAdd(&P.ctr[KVQ_CTR_RECORDS_], (unsigned long long)n);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// exhaustive matcher
+// ---------------------------------------------------------------------------
+
+// mismatches of x[0..n) vs y[0..n) stay within the budget?
+__device__ __forceinline__ bool within_budget(const uint8_t *x, const uint8_t *y, int n, int budget)
+{
+    int e = 0;
+    for (int j = 0; j < n; j++) {
+        e += (x[j] != y[j]);
+        if (e > budget) return false;
+    }
+    return e <= budget;
+}
+
+// one wave per read; lanes share out the alignments ("jobs") of the read
+// against one sequence: class A jobs, then class B, then class C.
+extern "C" __global__ void __launch_bounds__(256)
+kvq_match_all(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, uint32_t nrec,
+              const uint32_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+              const int32_t *__restrict__ seq_list, int32_t nlist)
+{
+    const int lane = kvq_lane();
+    const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (g >= nrec) return;
+    const int rl = read_len[g];
+    if (rl < 0) return;
+    const uint8_t *read = data + read_off[g];
+    const int64_t fpos = fpos_base + read_off[g];
+    const int mo = P.minoverlap, me = P.maxerrors;
+
+    for (int q = 0; q < nlist; q++) {
+        const int s = seq_list[q];
+        const uint8_t *seq = P.tab + P.tab_off[s];
+        const int seql = P.tab_off[s + 1] - P.tab_off[s];
+        // job ranges, in emission order
+        int nA = 0, nB = 0, iA_hi = 0, iB_hi = 0;
+        if (rl > mo && seql > mo) {
+            iA_hi = rl - mo;                                   // A: i = iA_hi .. iA_lo (1116)
+            const int iA_lo = (rl - seql + 1) > 1 ? (rl - seql + 1) : 1;
+            nA = iA_hi - iA_lo + 1; if (nA < 0) nA = 0;
+            iB_hi = seql - mo;                                 // B: i = iB_hi .. iB_lo (1130)
+            const int iB_lo = (seql - rl) > 1 ? (seql - rl) : 1;
+            nB = iB_hi - iB_lo + 1; if (nB < 0) nB = 0;
+        }
+        const int nC = (rl > seql ? rl - seql : seql - rl) + 1;   // 1147 / 1163
+        const int njobs = nA + nB + nC;
+        for (int j0 = 0; j0 < njobs; j0 += 64) {
+            const int j = j0 + lane;
+            bool hit = false; int spos = 0, len = 0; uint32_t key = 0;
+            if (j < njobs) {
+                if (j < nA) {                                  // tail of read over head of sequence
+                    const int i = iA_hi - j;
+                    len = rl - i; spos = -i; key = (0u << 30) | (uint32_t)j;
+                    hit = within_budget(read + i, seq, len, me);
+                } else if (j < nA + nB) {                      // head of read over tail of sequence
+                    const int i = iB_hi - (j - nA);
+                    len = seql - i; spos = i; key = (1u << 30) | (uint32_t)(j - nA);
+                    hit = within_budget(seq + i, read, len, me);
+                } else {
+                    const int i = j - nA - nB;
+                    key = (2u << 30) | (uint32_t)i;
+                    if (rl > seql) { len = seql; spos = -i; hit = within_budget(read + i, seq, len, me); }
+                    else           { len = rl;   spos = i;  hit = within_budget(seq + i, read, len, me); }
+                }
+            }
+            kvq_emit(P, hit, fpos, s, spos, len, rl, key);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// hit fold: counters, coverage/mutations, hit bytes
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ int base_class(uint8_t c)
+{
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : 5;
+}
+
+// hits [*range_begin, min(*range_end, cap)) of the arena, one thread per hit.
+extern "C" __global__ void __launch_bounds__(256)
+kvq_fold_hits(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base,
+              const unsigned int *__restrict__ range_begin, const unsigned int *__restrict__ range_end)
+{
+    const uint32_t h0 = *range_begin;
+    uint32_t h1 = *range_end; if (h1 > P.arena_cap) h1 = P.arena_cap;
+    for (uint32_t h = h0 + blockIdx.x * blockDim.x + threadIdx.x; h < h1; h += gridDim.x * blockDim.x) {
+        KvqHit hit = P.arena[h];
+        const int s = hit.seq_nr, len = hit.length;
+        atomicAdd(&P.ctr[P.off_nseqhits + s], 1ull);                                  // 435
+        atomicAdd(&P.ctr[P.off_nseqbasehits + s], (unsigned long long)len);           // 434
+        atomicAdd(&P.ctr[KVQ_CTR_HITS_], 1ull);
+        const int start = hit.seq_pos > 0 ? hit.seq_pos : 0;                          // analyse.py:70
+        const uint8_t *src = data + (hit.fpos - fpos_base) + (hit.seq_pos < 0 ? -hit.seq_pos : 0);
+        const uint8_t *seq = P.tab + P.tab_off[s] + start;
+        const int64_t at = (int64_t)P.tab_off[s] + start;
+        const unsigned long long boff = atomicAdd(P.blob_n, (unsigned long long)len);
+        const bool fits = boff + (unsigned long long)len <= P.blob_cap;
+        for (int j = 0; j < len; j++) {
+            const uint8_t c = src[j];
+            atomicAdd(&P.ctr[P.off_cov + at + j], 1ull);                              // analyse.py:76
+            if (c != seq[j]) atomicAdd(&P.ctr[P.off_mut + (at + j) * 6 + base_class(c)], 1ull);   // analyse.py:77-78
+            if (fits) P.blob[boff + j] = c;                                           // 437
+        }
+        P.arena[h].blob_off = fits ? (uint32_t)boff : 0xFFFFFFFFu;
+    }
+}

@@ -1,0 +1,105 @@
+// kvarq_amd/csrc/kvq_device.h -- structures and wave-level helpers shared by the
+// HIP kernels (gfx950 only: 64-lane wavefronts are assumed throughout).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KVQ_WAVE 64
+#define KVQ_SEG_BYTES 4096u   // one wave indexes 4 KiB of text: 4 rounds x 64 lanes x 16 B
+
+// one hit as the kernels emit it (32 bytes).  Canonical order of the
+// reference for one worker: by read, by sequence, then class A
+// (i descending), class B (i descending), class C (i ascending) --
+// key = class << 30 | ordinal inside the class.
+struct KvqHit {
+    int64_t  fpos;        // file_pos: stream offset of the first base of the trimmed read (workhorse.c:1124)
+    int32_t  seq_nr;
+    int32_t  seq_pos;
+    int32_t  length;
+    int32_t  readlength;
+    uint32_t key;
+    uint32_t blob_off;    // where kvq_fold_hits put the hit bytes
+};
+
+// counters layout (include/kvarq_hip.h)
+#define KVQ_CTR_RECORDS_ 0
+#define KVQ_CTR_LONGEST_ 1
+#define KVQ_CTR_HITS_ 2
+#define KVQ_CTR_RL_ 4
+#define KVQ_RL_BINS 1024
+
+// parameters every scanning kernel needs
+struct KvqParams {
+    int32_t maxerrors, minoverlap, minreadlength;
+    int32_t amin;                 // signed char value of Amin
+    int32_t nseq;                 // all sequences
+    const uint8_t *tab;           // concatenated sequence bytes
+    const int32_t *tab_off;       // nseq + 1 prefix sums
+    unsigned long long *ctr;      // counters (int64 slots)
+    int64_t off_nseqhits, off_nseqbasehits, off_cov, off_mut;
+    KvqHit *arena; uint32_t arena_cap;
+    unsigned int *arena_n;        // hits emitted so far (keeps counting past cap)
+    uint8_t *blob; unsigned long long blob_cap;
+    unsigned long long *blob_n;
+    unsigned long long *err;      // min over bad records of (fpos << 16 | kind << 8 | byte); ~0 = none
+};
+
+__device__ __forceinline__ int kvq_lane() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ uint64_t kvq_lanemask_lt()
+{
+    return (1ull << kvq_lane()) - 1ull;
+}
+
+// 0x80 in every byte of x that equals '\n' (exact per byte, no borrow artefacts)
+__device__ __forceinline__ uint32_t kvq_nl_flags(uint32_t x)
+{
+    const uint32_t y = x ^ 0x0A0A0A0Au;
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+}
+
+// 0x80 flags of the bytes of a dword at batch offset p that lie inside [a, b)
+__device__ __forceinline__ uint32_t kvq_range_flags(uint32_t p, uint32_t a, uint32_t b)
+{
+    long long lo = (long long)a - (long long)p, hi = (long long)b - (long long)p;
+    lo = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
+    hi = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
+    if (hi <= lo) return 0u;
+    const uint64_t m = ((1ull << (8 * hi)) - 1ull) & ~((1ull << (8 * lo)) - 1ull);
+    return (uint32_t)m & 0x80808080u;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t kvq_wave_incl_scan(uint32_t v)
+{
+    const int lane = kvq_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// append one hit per flagged lane to the arena with a single atomic per wave.
+// Must be called by all lanes of the wave (convergent).
+__device__ __forceinline__ void kvq_emit(const KvqParams &P, bool hit, int64_t fpos, int seq_nr,
+                                         int seq_pos, int length, int rl, uint32_t key)
+{
+    const uint64_t m = __ballot(hit);
+    if (m == 0) return;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (kvq_lane() == leader) base = atomicAdd(P.arena_n, (unsigned int)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (hit) {
+        const uint32_t idx = base + (uint32_t)__popcll(m & kvq_lanemask_lt());
+        if (idx < P.arena_cap) {
+            KvqHit h;
+            h.fpos = fpos; h.seq_nr = seq_nr; h.seq_pos = seq_pos; h.length = length;
+            h.readlength = rl; h.key = key; h.blob_off = 0;
+            P.arena[idx] = h;
+        }
+    }
+}

@@ -1,0 +1,94 @@
+// kvarq_amd/csrc/kvq_host.h -- host-side internals of libkvarq_hip.so
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/kvarq_hip.h"
+#include "kvq_device.h"
+
+// ---- error state (thread local) ----------------------------------------------
+void kvq_set_error(int code, const char *fmt, ...);
+void kvq_clear_error();
+int  kvq_error_code();
+
+#define KVQ_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            kvq_set_error(KVQ_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return KVQ_ERR_DEVICE;                                                            \
+        }                                                                                     \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t n);          // KVQ_OK / error code; contents are NOT preserved
+    void release();
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct kvq_table {
+    kvq_config cfg;
+    int32_t nseq = 0;
+    int64_t bases = 0;
+    std::vector<uint8_t> h_tab;          // concatenated bytes
+    std::vector<int32_t> h_off;          // nseq + 1
+    std::vector<int32_t> exhaustive;     // sequences the exhaustive kernel serves
+    std::vector<int32_t> seeded;         // sequences the seed-filter kernel serves
+    std::vector<uint8_t> is_seeded;
+    int32_t seed_k = 0;
+    DevBuf d_tab, d_off, d_exh, d_all;
+    struct SeedIndex *index = nullptr;   // kernels_seeded
+    int64_t ctr_len, off_nseqhits, off_nseqbasehits, off_cov, off_mut;
+};
+
+struct Batch {
+    const uint8_t *d_data; int64_t nbytes; int64_t fpos_base;
+    std::vector<int64_t> chunk_off;
+};
+
+struct kvq_scan {
+    const kvq_table *t = nullptr;
+    hipStream_t stream = nullptr;
+    bool force_exhaustive = false;
+    // counters
+    unsigned long long *d_ctr = nullptr; bool own_ctr = false;
+    std::vector<int64_t> h_ctr;
+    // per-batch scratch
+    DevBuf d_chunk_off, d_seg_base, d_seg_cnt, d_chunk_nrec, d_rec_base, d_nl4, d_rec_start, d_read_off, d_read_len;
+    // hit arena
+    DevBuf d_arena, d_blob, d_small;   // d_small: arena_n, batch range words, blob_n, err
+    uint32_t arena_cap = 0; uint64_t blob_cap = 0;
+    unsigned int *d_arena_n = nullptr, *d_range = nullptr; unsigned long long *d_blob_n = nullptr, *d_err = nullptr;
+    // staging for host batches
+    DevBuf d_stage;
+    // replay list (device batches) + bookkeeping
+    std::vector<Batch> batches;
+    bool host_batches = false;
+    int64_t records = 0;
+    int64_t parsed = 0, total = 0;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_all, ev_main;
+    double ms_all = 0, ms_main = 0; int64_t main_launches = 0;
+    // results on the host
+    std::vector<int32_t> r_seq_nr, r_seq_pos, r_length, r_readlength;
+    std::vector<int64_t> r_file_pos, r_hitseq_off;
+    std::vector<uint8_t> r_blob;
+    bool finished = false;
+};
+
+// kernels_seeded.hip
+struct SeedIndex;
+SeedIndex *kvq_seed_index_build(kvq_table *t);           // nullptr when no sequence qualifies
+void       kvq_seed_index_destroy(SeedIndex *ix);
+// enqueue the fused seed-filter scan of one batch; returns KVQ_OK or error
+int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
+                      const uint32_t *d_chunk_off, int64_t nchunks, int64_t fpos_base, uint32_t max_chunk_bytes);
+
+// synth.hip
+// (C ABI only)

@@ -1,0 +1,536 @@
+// kvarq_amd/csrc/kvq_runtime.hip -- host runtime of libkvarq_hip.so: config and
+// error state, the target table, the scan object (batches -> kernels -> hits),
+// results.  The file reader / engine.findseqs driver lives in kvq_findseqs.hip.
+#include "kvq_host.h"
+
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <stdarg.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------
+// error state and config
+// ---------------------------------------------------------------------------
+
+static thread_local int  tl_err_code = 0;
+static thread_local char tl_err_msg[1024] = "";
+
+void kvq_set_error(int code, const char *fmt, ...)
+{
+    tl_err_code = code;
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(tl_err_msg, sizeof(tl_err_msg), fmt, ap);
+    va_end(ap);
+}
+void kvq_clear_error() { tl_err_code = 0; tl_err_msg[0] = 0; }
+int  kvq_error_code() { return tl_err_code; }
+
+extern "C" int32_t kvq_last_error(char *msg, size_t cap)
+{
+    if (msg && cap) { strncpy(msg, tl_err_msg, cap - 1); msg[cap - 1] = 0; }
+    return tl_err_code;
+}
+
+static std::mutex g_cfg_lock;
+static kvq_config g_cfg = { 0, 20, 10, 1, '!', '!' };      // workhorse.c:71-75
+
+extern "C" void kvq_config_set(const kvq_config *cfg) { std::lock_guard<std::mutex> l(g_cfg_lock); g_cfg = *cfg; }
+extern "C" void kvq_config_get(kvq_config *cfg) { std::lock_guard<std::mutex> l(g_cfg_lock); *cfg = g_cfg; }
+extern "C" const char *kvq_version(void) { return "kvarq_hip 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------
+// device plumbing
+// ---------------------------------------------------------------------------
+
+int DevBuf::ensure(size_t n)
+{
+    if (n <= cap && p) return KVQ_OK;
+    size_t want = n + n / 4 + 256;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        kvq_set_error(e == hipErrorOutOfMemory ? KVQ_ERR_MEMORY : KVQ_ERR_DEVICE, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return tl_err_code;
+    }
+    cap = want;
+    return KVQ_OK;
+}
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+
+extern "C" int32_t kvq_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int32_t kvq_set_device(int32_t o) { KVQ_HIP(hipSetDevice(o)); return KVQ_OK; }
+extern "C" void *kvq_device_alloc(int64_t n)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, (size_t)n + 256) != hipSuccess) { kvq_set_error(KVQ_ERR_MEMORY, "hipMalloc(%lld) failed", (long long)n); return nullptr; }
+    return p;
+}
+extern "C" void kvq_device_free(void *p) { if (p) (void)hipFree(p); }
+extern "C" int32_t kvq_memcpy_h2d(void *d, const void *h, int64_t n) { KVQ_HIP(hipMemcpy(d, h, (size_t)n, hipMemcpyHostToDevice)); return KVQ_OK; }
+extern "C" int32_t kvq_memcpy_d2h(void *h, const void *d, int64_t n) { KVQ_HIP(hipMemcpy(h, d, (size_t)n, hipMemcpyDeviceToHost)); return KVQ_OK; }
+extern "C" int32_t kvq_memset_d(void *d, int32_t v, int64_t n) { KVQ_HIP(hipMemset(d, v, (size_t)n)); return KVQ_OK; }
+extern "C" int32_t kvq_device_synchronize(void) { KVQ_HIP(hipDeviceSynchronize()); return KVQ_OK; }
+
+// ---------------------------------------------------------------------------
+// table
+// ---------------------------------------------------------------------------
+
+extern "C" kvq_table *kvq_table_create(const uint8_t *const *seqs, const int32_t *seqlens, int32_t nseq, const kvq_config *cfg)
+{
+    kvq_clear_error();
+    if (kvq_device_count() <= 0) { kvq_set_error(KVQ_ERR_DEVICE, "no HIP device available: libkvarq_hip has no CPU path"); return nullptr; }
+    kvq_table *t = new kvq_table();
+    if (cfg) t->cfg = *cfg; else kvq_config_get(&t->cfg);
+    t->nseq = nseq;
+    t->h_off.resize((size_t)nseq + 1);
+    int64_t tot = 0;
+    for (int i = 0; i < nseq; i++) {
+        if (seqlens[i] < 0) { kvq_set_error(KVQ_ERR_TYPE, "seqlist must be list of strings"); delete t; return nullptr; }
+        t->h_off[i] = (int32_t)tot; tot += seqlens[i];
+        if (tot > 0x7FFFFFFF) { kvq_set_error(KVQ_ERR_MEMORY, "sequence table too large"); delete t; return nullptr; }
+    }
+    t->h_off[nseq] = (int32_t)tot;
+    t->bases = tot;
+    t->h_tab.resize((size_t)tot + 64, 0);
+    for (int i = 0; i < nseq; i++) if (seqlens[i]) memcpy(&t->h_tab[t->h_off[i]], seqs[i], (size_t)seqlens[i]);
+    // counters layout (include/kvarq_hip.h)
+    t->off_nseqhits = KVQ_CTR_RL_ + KVQ_RL_BINS;
+    t->off_nseqbasehits = t->off_nseqhits + nseq;
+    t->off_cov = t->off_nseqbasehits + nseq;
+    t->off_mut = t->off_cov + tot;
+    t->ctr_len = t->off_mut + 6 * tot;
+
+    t->is_seeded.assign((size_t)nseq, 0);
+    t->index = kvq_seed_index_build(t);      // fills seeded / is_seeded / seed_k
+    if (kvq_error_code()) { kvq_table_destroy(t); return nullptr; }
+    for (int i = 0; i < nseq; i++) if (!t->is_seeded[i]) t->exhaustive.push_back(i);
+
+    std::vector<int32_t> all((size_t)nseq);
+    for (int i = 0; i < nseq; i++) all[i] = i;
+    bool ok = t->d_tab.ensure(t->h_tab.size()) == KVQ_OK && t->d_off.ensure((size_t)(nseq + 1) * 4) == KVQ_OK &&
+              t->d_exh.ensure((size_t)(nseq + 1) * 4) == KVQ_OK && t->d_all.ensure((size_t)(nseq + 1) * 4) == KVQ_OK;
+    if (ok) {
+        ok = hipMemcpy(t->d_tab.p, t->h_tab.data(), t->h_tab.size(), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(t->d_off.p, t->h_off.data(), (size_t)(nseq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             (t->exhaustive.empty() || hipMemcpy(t->d_exh.p, t->exhaustive.data(), t->exhaustive.size() * 4, hipMemcpyHostToDevice) == hipSuccess) &&
+             (nseq == 0 || hipMemcpy(t->d_all.p, all.data(), (size_t)nseq * 4, hipMemcpyHostToDevice) == hipSuccess);
+        if (!ok) kvq_set_error(KVQ_ERR_DEVICE, "uploading the sequence table failed");
+    }
+    if (!ok) { kvq_table_destroy(t); return nullptr; }
+    return t;
+}
+
+extern "C" void kvq_table_destroy(kvq_table *t)
+{
+    if (!t) return;
+    if (t->index) kvq_seed_index_destroy(t->index);
+    t->d_tab.release(); t->d_off.release(); t->d_exh.release(); t->d_all.release();
+    delete t;
+}
+extern "C" int32_t kvq_table_nseq(const kvq_table *t) { return t->nseq; }
+extern "C" int64_t kvq_table_bases(const kvq_table *t) { return t->bases; }
+extern "C" int32_t kvq_table_seq_is_seeded(const kvq_table *t, int32_t s) { return (s >= 0 && s < t->nseq) ? t->is_seeded[s] : 0; }
+extern "C" int32_t kvq_table_seed_k(const kvq_table *t) { return t->seed_k; }
+extern "C" int64_t kvq_counters_len(const kvq_table *t) { return t->ctr_len; }
+extern "C" int64_t kvq_counters_off_nseqhits(const kvq_table *t) { return t->off_nseqhits; }
+extern "C" int64_t kvq_counters_off_nseqbasehits(const kvq_table *t) { return t->off_nseqbasehits; }
+extern "C" int64_t kvq_counters_off_coverage(const kvq_table *t) { return t->off_cov; }
+extern "C" int64_t kvq_counters_off_mutations(const kvq_table *t) { return t->off_mut; }
+extern "C" int64_t kvq_table_seq_offset(const kvq_table *t, int32_t s) { return (s >= 0 && s <= t->nseq) ? t->h_off[s] : -1; }
+
+// ---------------------------------------------------------------------------
+// scan object
+// ---------------------------------------------------------------------------
+
+#define KVQ_MAX_BATCHES 65536
+// d_small layout (bytes): [0] arena_n u32, [8] blob_n u64, [16] err u64, [64 ..) range words u32 x (KVQ_MAX_BATCHES+1)
+static const size_t SMALL_BYTES = 64 + 4 * (KVQ_MAX_BATCHES + 1);
+
+static int reset_device_state(kvq_scan *s)
+{
+    KVQ_HIP(hipMemsetAsync(s->d_small.p, 0, SMALL_BYTES, s->stream));
+    KVQ_HIP(hipMemsetAsync(s->d_err, 0xFF, 8, s->stream));
+    KVQ_HIP(hipMemsetAsync(s->d_ctr, 0, (size_t)s->t->ctr_len * 8, s->stream));
+    return KVQ_OK;
+}
+
+static int ensure_arena(kvq_scan *s, uint64_t hits, uint64_t blob)
+{
+    if (hits > 0xFFFFFFF0ull) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); return KVQ_ERR_MEMORY; }
+    if (hits > s->arena_cap) {
+        int rc = s->d_arena.ensure((size_t)hits * sizeof(KvqHit)); if (rc) return rc;
+        s->arena_cap = (uint32_t)hits;
+    }
+    if (blob > s->blob_cap) {
+        if (blob > 0xFFFFFFF0ull) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); return KVQ_ERR_MEMORY; }
+        int rc = s->d_blob.ensure((size_t)blob); if (rc) return rc;
+        s->blob_cap = blob;
+    }
+    return KVQ_OK;
+}
+
+extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
+{
+    kvq_clear_error();
+    kvq_scan *s = new kvq_scan();
+    s->t = t;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        kvq_set_error(KVQ_ERR_DEVICE, "hipStreamCreate failed"); delete s; return nullptr;
+    }
+    if (d_counters) { s->d_ctr = (unsigned long long *)d_counters; s->own_ctr = false; }
+    else {
+        if (hipMalloc((void **)&s->d_ctr, (size_t)t->ctr_len * 8) != hipSuccess) { kvq_set_error(KVQ_ERR_MEMORY, "hipMalloc(counters) failed"); kvq_scan_destroy(s); return nullptr; }
+        s->own_ctr = true;
+    }
+    if (s->d_small.ensure(SMALL_BYTES) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
+    s->d_arena_n = (unsigned int *)s->d_small.p;
+    s->d_blob_n = (unsigned long long *)((char *)s->d_small.p + 8);
+    s->d_err = (unsigned long long *)((char *)s->d_small.p + 16);
+    s->d_range = (unsigned int *)((char *)s->d_small.p + 64);
+    if (ensure_arena(s, 1u << 20, 64ull << 20) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
+    if (reset_device_state(s) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
+    s->h_ctr.assign((size_t)t->ctr_len, 0);
+    return s;
+}
+
+static void drop_events(kvq_scan *s)
+{
+    for (auto &e : s->ev_all) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : s->ev_main) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    s->ev_all.clear(); s->ev_main.clear();
+}
+
+extern "C" void kvq_scan_destroy(kvq_scan *s)
+{
+    if (!s) return;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    drop_events(s);
+    if (s->own_ctr && s->d_ctr) (void)hipFree(s->d_ctr);
+    DevBuf *bufs[] = { &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
+                       &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
+    for (DevBuf *b : bufs) b->release();
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" void kvq_scan_force_exhaustive(kvq_scan *s, int32_t on) { s->force_exhaustive = on != 0; }
+
+extern "C" int32_t kvq_scan_reset(kvq_scan *s)
+{
+    kvq_clear_error();
+    KVQ_HIP(hipStreamSynchronize(s->stream));
+    drop_events(s);
+    s->batches.clear(); s->host_batches = false; s->records = 0; s->parsed = 0; s->total = 0;
+    s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false;
+    return reset_device_state(s);
+}
+
+static KvqParams make_params(const kvq_scan *s)
+{
+    const kvq_table *t = s->t;
+    KvqParams P;
+    P.maxerrors = t->cfg.maxerrors; P.minoverlap = t->cfg.minoverlap; P.minreadlength = t->cfg.minreadlength;
+    P.amin = (int32_t)t->cfg.Amin; P.nseq = t->nseq;
+    P.tab = t->d_tab.as<uint8_t>(); P.tab_off = t->d_off.as<int32_t>();
+    P.ctr = s->d_ctr;
+    P.off_nseqhits = t->off_nseqhits; P.off_nseqbasehits = t->off_nseqbasehits; P.off_cov = t->off_cov; P.off_mut = t->off_mut;
+    P.arena = s->d_arena.as<KvqHit>(); P.arena_cap = s->arena_cap; P.arena_n = s->d_arena_n;
+    P.blob = s->d_blob.as<uint8_t>(); P.blob_cap = s->blob_cap; P.blob_n = s->d_blob_n;
+    P.err = s->d_err;
+    return P;
+}
+
+static int new_event_pair(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v)
+{
+    hipEvent_t a, b;
+    KVQ_HIP(hipEventCreate(&a)); KVQ_HIP(hipEventCreate(&b));
+    v.emplace_back(a, b);
+    return KVQ_OK;
+}
+
+// enqueue every kernel of one batch.  The exhaustive path needs one host
+// round trip (records per chunk) to size its record arrays.
+static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks,
+                     int64_t fpos_base, size_t batch_no)
+{
+    const kvq_table *t = s->t;
+    if (nbytes <= 0 || nchunks <= 0) return KVQ_OK;
+    if (nbytes >= (1ll << 31)) { kvq_set_error(KVQ_ERR_RUNTIME, "batch of %lld bytes is too large (< 2 GiB)", (long long)nbytes); return KVQ_ERR_RUNTIME; }
+    if (batch_no >= KVQ_MAX_BATCHES) { kvq_set_error(KVQ_ERR_RUNTIME, "too many batches in one scan"); return KVQ_ERR_RUNTIME; }
+    if (((uintptr_t)d_data & 15u) != 0) { kvq_set_error(KVQ_ERR_RUNTIME, "device buffer must be 16-byte aligned"); return KVQ_ERR_RUNTIME; }
+
+    KvqParams P = make_params(s);
+    const bool use_seeded = t->index && !t->seeded.empty() && !s->force_exhaustive;
+    const std::vector<int32_t> *exh = &t->exhaustive;
+    const int32_t *d_exh = t->d_exh.as<int32_t>();
+    std::vector<int32_t> all;
+    if (!use_seeded) { d_exh = t->d_all.as<int32_t>(); }
+    const int32_t n_exh = use_seeded ? (int32_t)exh->size() : t->nseq;
+
+    // chunk table
+    std::vector<uint32_t> co((size_t)nchunks + 1), sb((size_t)nchunks + 1);
+    uint32_t maxseg = 0, maxchunk = 0; uint64_t segs = 0;
+    for (int64_t c = 0; c <= nchunks; c++) {
+        if (chunk_off[c] < 0 || chunk_off[c] > nbytes || (c && chunk_off[c] < chunk_off[c - 1])) {
+            kvq_set_error(KVQ_ERR_RUNTIME, "bad chunk offsets"); return KVQ_ERR_RUNTIME;
+        }
+        co[c] = (uint32_t)chunk_off[c];
+    }
+    for (int64_t c = 0; c < nchunks; c++) {
+        const uint32_t a = co[c], b = co[c + 1];
+        const uint32_t n = b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + KVQ_SEG_BYTES - 1) / KVQ_SEG_BYTES) : 0u;
+        sb[c] = (uint32_t)segs; segs += n;
+        maxseg = std::max(maxseg, n); maxchunk = std::max(maxchunk, b - a);
+    }
+    sb[nchunks] = (uint32_t)segs;
+    int rc;
+    if ((rc = s->d_chunk_off.ensure(co.size() * 4))) return rc;
+    KVQ_HIP(hipMemcpyAsync(s->d_chunk_off.p, co.data(), co.size() * 4, hipMemcpyHostToDevice, s->stream));
+    KVQ_HIP(hipStreamSynchronize(s->stream));      // co is a local: the copy must be done before it dies
+
+    if ((rc = new_event_pair(s->ev_all))) return rc;
+    KVQ_HIP(hipEventRecord(s->ev_all.back().first, s->stream));
+
+    bool hist_done = false;
+    if (use_seeded) {
+        if ((rc = new_event_pair(s->ev_main))) return rc;
+        KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream));
+        if ((rc = kvq_seeded_launch(s, P, d_data, nbytes, s->d_chunk_off.as<uint32_t>(), nchunks, fpos_base, maxchunk))) return rc;
+        KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
+        s->main_launches++;
+        hist_done = true;
+    }
+
+    if (!hist_done || n_exh > 0) {
+        if ((rc = s->d_seg_base.ensure(sb.size() * 4))) return rc;
+        if ((rc = s->d_seg_cnt.ensure((size_t)(segs + 1) * 4))) return rc;
+        if ((rc = s->d_chunk_nrec.ensure((size_t)(nchunks + 1) * 4))) return rc;
+        if ((rc = s->d_rec_base.ensure((size_t)(nchunks + 1) * 4))) return rc;
+        KVQ_HIP(hipMemcpyAsync(s->d_seg_base.p, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, s->stream));
+        const uint32_t gx = std::max(1u, std::min(65u, (maxseg + 3) / 4));
+        for (int64_t c0 = 0; c0 < nchunks; c0 += 32768) {
+            const uint32_t ny = (uint32_t)std::min<int64_t>(32768, nchunks - c0);
+            hipLaunchKernelGGL(kvq_count_lines, dim3(gx, ny), dim3(256), 0, s->stream, d_data,
+                               s->d_chunk_off.as<uint32_t>() + c0, s->d_seg_base.as<uint32_t>() + c0, s->d_seg_cnt.as<uint32_t>());
+        }
+        hipLaunchKernelGGL(kvq_scan_segments, dim3((uint32_t)((nchunks + 3) / 4)), dim3(256), 0, s->stream, (uint32_t)nchunks,
+                           s->d_seg_base.as<uint32_t>(), s->d_seg_cnt.as<uint32_t>(), s->d_chunk_nrec.as<uint32_t>());
+        std::vector<uint32_t> nrec((size_t)nchunks), rbase((size_t)nchunks + 1);
+        KVQ_HIP(hipMemcpyAsync(nrec.data(), s->d_chunk_nrec.p, (size_t)nchunks * 4, hipMemcpyDeviceToHost, s->stream));
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        uint64_t R = 0;
+        for (int64_t c = 0; c < nchunks; c++) { rbase[c] = (uint32_t)R; R += nrec[c]; }
+        rbase[nchunks] = (uint32_t)R;
+        if (R > 0) {
+            if ((rc = s->d_nl4.ensure((size_t)R * 16))) return rc;
+            if ((rc = s->d_rec_start.ensure((size_t)R * 4))) return rc;
+            if ((rc = s->d_read_off.ensure((size_t)R * 4))) return rc;
+            if ((rc = s->d_read_len.ensure((size_t)R * 4))) return rc;
+            KVQ_HIP(hipMemcpyAsync(s->d_rec_base.p, rbase.data(), rbase.size() * 4, hipMemcpyHostToDevice, s->stream));
+            KVQ_HIP(hipStreamSynchronize(s->stream));
+            for (int64_t c0 = 0; c0 < nchunks; c0 += 32768) {
+                const uint32_t ny = (uint32_t)std::min<int64_t>(32768, nchunks - c0);
+                hipLaunchKernelGGL(kvq_index_records, dim3(gx, ny), dim3(256), 0, s->stream, d_data,
+                                   s->d_chunk_off.as<uint32_t>() + c0, s->d_seg_base.as<uint32_t>() + c0, s->d_seg_cnt.as<uint32_t>(),
+                                   s->d_chunk_nrec.as<uint32_t>() + c0, s->d_rec_base.as<uint32_t>() + c0,
+                                   s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>());
+            }
+            const uint32_t per_block = 4 * 16;       // KVQ_TRIM_RPW records per wave
+            hipLaunchKernelGGL(kvq_trim_records, dim3((uint32_t)((R + per_block - 1) / per_block)), dim3(256), 0, s->stream, P, d_data,
+                               fpos_base, (uint32_t)R, s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(),
+                               s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), hist_done ? 0 : 1);
+            if (n_exh > 0) {
+                const bool main_here = !use_seeded;
+                if (main_here) { if ((rc = new_event_pair(s->ev_main))) return rc; KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream)); }
+                hipLaunchKernelGGL(kvq_match_all, dim3((uint32_t)((R + 3) / 4)), dim3(256), 0, s->stream, P, d_data, fpos_base, (uint32_t)R,
+                                   s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), d_exh, n_exh);
+                if (main_here) { KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream)); s->main_launches++; }
+            }
+        }
+    }
+    // hits of this batch = arena[range[batch_no], range[batch_no + 1])
+    KVQ_HIP(hipMemcpyAsync(s->d_range + batch_no + 1, s->d_arena_n, 4, hipMemcpyDeviceToDevice, s->stream));
+    hipLaunchKernelGGL(kvq_fold_hits, dim3(64), dim3(256), 0, s->stream, P, d_data, fpos_base,
+                       (const unsigned int *)(s->d_range + batch_no), (const unsigned int *)(s->d_range + batch_no + 1));
+    KVQ_HIP(hipEventRecord(s->ev_all.back().second, s->stream));
+    KVQ_HIP(hipGetLastError());
+    return KVQ_OK;
+}
+
+extern "C" int32_t kvq_scan_device(kvq_scan *s, const void *d_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base)
+{
+    kvq_clear_error();
+    Batch b; b.d_data = (const uint8_t *)d_data; b.nbytes = nbytes; b.fpos_base = fpos_base;
+    b.chunk_off.assign(chunk_off, chunk_off + nchunks + 1);
+    s->batches.push_back(b);
+    s->parsed += nbytes; s->total += nbytes;
+    return run_batch(s, (const uint8_t *)d_data, nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1);
+}
+
+extern "C" int32_t kvq_scan_host(kvq_scan *s, const void *h_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base)
+{
+    kvq_clear_error();
+    if (nbytes <= 0) return KVQ_OK;
+    // the staging buffer is reused: the previous batch must have drained
+    KVQ_HIP(hipStreamSynchronize(s->stream));
+    int rc = s->d_stage.ensure((size_t)nbytes + 64); if (rc) return rc;
+    KVQ_HIP(hipMemcpyAsync(s->d_stage.p, h_data, (size_t)nbytes, hipMemcpyHostToDevice, s->stream));
+    Batch b; b.d_data = nullptr; b.nbytes = nbytes; b.fpos_base = fpos_base;
+    s->batches.push_back(b);
+    s->host_batches = true;
+    s->parsed += nbytes; s->total += nbytes;
+    return run_batch(s, s->d_stage.as<uint8_t>(), nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1);
+}
+
+// internal: arena too small; the caller must rescan (sizes are in the scan object)
+#define KVQ_NEED_RESCAN (-2)
+
+static int finish_once(kvq_scan *s)
+{
+    KVQ_HIP(hipStreamSynchronize(s->stream));
+    unsigned char small[24];
+    KVQ_HIP(hipMemcpy(small, s->d_small.p, 24, hipMemcpyDeviceToHost));
+    unsigned int n_hits; unsigned long long blob_n, err;
+    memcpy(&n_hits, small, 4); memcpy(&blob_n, small + 8, 8); memcpy(&err, small + 16, 8);
+    if (err != ~0ull) {
+        // first malformed record in stream order (workhorse.c:1037-1048)
+        const long fpos = (long)(err >> 16); const int kind = (int)((err >> 8) & 0xFF); const int ch = (int)(err & 0xFF);
+        if (kind == 0) kvq_set_error(KVQ_ERR_FORMAT, "record must start with '@' (and not '%c') fpos=%ld", ch, fpos);
+        else kvq_set_error(KVQ_ERR_FORMAT, "3rd line of record must start with '+' fpos=%ld", fpos);
+        return KVQ_ERR_FORMAT;
+    }
+    if (n_hits > s->arena_cap || blob_n > s->blob_cap) {
+        // grow to what this scan needs and ask for a rescan
+        const uint64_t want_hits = std::max<uint64_t>(n_hits + n_hits / 8 + 1024, s->arena_cap);
+        // blob_n undercounts when the arena overflowed (dropped hits were never folded): scale it
+        uint64_t want_blob = blob_n;
+        if (n_hits > s->arena_cap && s->arena_cap) want_blob = (uint64_t)((double)blob_n * ((double)n_hits / s->arena_cap) * 1.25) + (1 << 20);
+        want_blob = std::max<uint64_t>(want_blob + want_blob / 8, s->blob_cap);
+        int rc = ensure_arena(s, want_hits, want_blob); if (rc) return rc;
+        return KVQ_NEED_RESCAN;
+    }
+    // results to the host
+    std::vector<KvqHit> hits(n_hits);
+    if (n_hits) KVQ_HIP(hipMemcpy(hits.data(), s->d_arena.p, (size_t)n_hits * sizeof(KvqHit), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> blob((size_t)blob_n);
+    if (blob_n) KVQ_HIP(hipMemcpy(blob.data(), s->d_blob.p, (size_t)blob_n, hipMemcpyDeviceToHost));
+    KVQ_HIP(hipMemcpy(s->h_ctr.data(), s->d_ctr, (size_t)s->t->ctr_len * 8, hipMemcpyDeviceToHost));
+
+    std::vector<uint32_t> order(n_hits);
+    for (uint32_t i = 0; i < n_hits; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const KvqHit &a = hits[x], &b = hits[y];
+        if (a.fpos != b.fpos) return a.fpos < b.fpos;
+        if (a.seq_nr != b.seq_nr) return a.seq_nr < b.seq_nr;
+        return a.key < b.key;
+    });
+    s->r_seq_nr.resize(n_hits); s->r_seq_pos.resize(n_hits); s->r_length.resize(n_hits); s->r_readlength.resize(n_hits);
+    s->r_file_pos.resize(n_hits); s->r_hitseq_off.resize((size_t)n_hits + 1); s->r_blob.resize((size_t)blob_n);
+    int64_t at = 0;
+    for (uint32_t i = 0; i < n_hits; i++) {
+        const KvqHit &h = hits[order[i]];
+        s->r_seq_nr[i] = h.seq_nr; s->r_file_pos[i] = h.fpos; s->r_seq_pos[i] = h.seq_pos; s->r_length[i] = h.length; s->r_readlength[i] = h.readlength;
+        s->r_hitseq_off[i] = at;
+        if (h.length > 0) memcpy(&s->r_blob[(size_t)at], &blob[h.blob_off], (size_t)h.length);
+        at += h.length;
+    }
+    s->r_hitseq_off[n_hits] = at;
+
+    s->ms_all = s->ms_main = 0;
+    for (auto &e : s->ev_all) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_all += ms; }
+    for (auto &e : s->ev_main) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_main += ms; }
+    s->finished = true;
+    return KVQ_OK;
+}
+
+// returns KVQ_OK, an error code, or KVQ_NEED_RESCAN when host batches must be fed again
+int kvq_scan_finish_internal(kvq_scan *s)
+{
+    for (int attempt = 0; attempt < 4; attempt++) {
+        int rc = finish_once(s);
+        if (rc != KVQ_NEED_RESCAN) return rc;
+        if (s->host_batches) return KVQ_NEED_RESCAN;
+        // device batches are still resident: replay them into the larger arena
+        std::vector<Batch> again; again.swap(s->batches);
+        drop_events(s); s->main_launches = 0;
+        if ((rc = reset_device_state(s))) return rc;
+        for (size_t b = 0; b < again.size(); b++) {
+            s->batches.push_back(again[b]);
+            rc = run_batch(s, again[b].d_data, again[b].nbytes, again[b].chunk_off.data(), (int64_t)again[b].chunk_off.size() - 1, again[b].fpos_base, b);
+            if (rc) return rc;
+        }
+    }
+    kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results");
+    return KVQ_ERR_MEMORY;
+}
+
+extern "C" int32_t kvq_scan_finish(kvq_scan *s)
+{
+    kvq_clear_error();
+    int rc = kvq_scan_finish_internal(s);
+    if (rc == KVQ_NEED_RESCAN) { kvq_set_error(KVQ_ERR_MEMORY, "hit arena overflow on host batches: rescan required"); return KVQ_ERR_MEMORY; }
+    return rc;
+}
+
+extern "C" int64_t kvq_scan_n_hits(const kvq_scan *s) { return (int64_t)s->r_seq_nr.size(); }
+extern "C" const int32_t *kvq_scan_hit_seq_nr(const kvq_scan *s) { return s->r_seq_nr.data(); }
+extern "C" const int64_t *kvq_scan_hit_file_pos(const kvq_scan *s) { return s->r_file_pos.data(); }
+extern "C" const int32_t *kvq_scan_hit_seq_pos(const kvq_scan *s) { return s->r_seq_pos.data(); }
+extern "C" const int32_t *kvq_scan_hit_length(const kvq_scan *s) { return s->r_length.data(); }
+extern "C" const int32_t *kvq_scan_hit_readlength(const kvq_scan *s) { return s->r_readlength.data(); }
+extern "C" const uint8_t *kvq_scan_hitseq_blob(const kvq_scan *s) { return s->r_blob.data(); }
+extern "C" const int64_t *kvq_scan_hitseq_offsets(const kvq_scan *s) { return s->r_hitseq_off.data(); }
+extern "C" const int64_t *kvq_scan_counters(const kvq_scan *s) { return s->h_ctr.data(); }
+extern "C" void *kvq_scan_device_counters(const kvq_scan *s) { return s->d_ctr; }
+extern "C" int64_t kvq_scan_parsed(const kvq_scan *s) { return s->parsed; }
+extern "C" int64_t kvq_scan_total(const kvq_scan *s) { return s->total; }
+extern "C" double kvq_scan_kernel_ms(const kvq_scan *s) { return s->ms_all; }
+extern "C" double kvq_scan_main_kernel_ms(const kvq_scan *s) { return s->ms_main; }
+extern "C" int64_t kvq_scan_main_kernel_launches(const kvq_scan *s) { return s->main_launches; }
+
+// ---------------------------------------------------------------------------
+// fastq_rewind / fastq_read chunk cuts on an in-memory stream
+// ---------------------------------------------------------------------------
+
+// length of the trailing partial record of buf[0..n): going backwards, the
+// first line start '@' met after a line start '+' (workhorse.c:696-718)
+int64_t kvq_tail_record(const uint8_t *buf, int64_t n)
+{
+    bool plus_seen = false;
+    for (int64_t k = n - 1; k >= 2; k--) {                 // i = n - k runs 1 .. n-2 (706)
+        const uint8_t prev = buf[k - 1];
+        if (prev != '\n' && prev != '\r') continue;
+        if (buf[k] == '+') plus_seen = true;
+        else if (buf[k] == '@' && plus_seen) return n - k;
+    }
+    return -1;
+}
+
+extern "C" int64_t kvq_chunk_offsets(const uint8_t *data, int64_t nbytes, int64_t *offsets, int64_t cap)
+{
+    int64_t n = 0, cs = 0, fill = 0;
+    for (;;) {
+        const int64_t want = KVQ_SCANBUFSIZE - (fill - cs);
+        const int64_t have = nbytes - fill;
+        if (have >= want) {                                // buffer filled, source not dry: cut (916-943)
+            const int64_t end = fill + want;
+            const int64_t keep = kvq_tail_record(data + cs, end - cs);
+            if (keep < 0) return -1;
+            if (n < cap) offsets[n] = cs;
+            n++;
+            cs = end - keep; fill = end;
+        } else {                                           // short read: eof, no cut (901-910)
+            if (nbytes > cs) { if (n < cap) offsets[n] = cs; n++; }
+            break;
+        }
+    }
+    if (n < cap + 1) offsets[n] = nbytes;
+    return n;
+}

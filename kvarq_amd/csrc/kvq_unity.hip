@@ -1,0 +1,7 @@
+// single translation unit of libkvarq_hip.so (kernels and their launch sites
+// must share one HIP module)
+#include "kernels_general.hip"
+#include "kernels_seeded.hip"
+#include "synth.hip"
+#include "kvq_runtime.hip"
+#include "kvq_findseqs.hip"

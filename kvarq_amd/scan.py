@@ -1,0 +1,176 @@
+"""
+Object view of the scan C ABI (include/kvarq_hip.h) for callers that keep data
+resident on the GPU: ``Table`` (the sequence list of ``engine.findseqs`` with
+its seed index) and ``Scanner`` (``scan_filepart`` of the reference,
+csrc/workhorse.c:976-1197, over batches that are already in device or host
+memory).  ``engine.findseqs`` is the file-level entry; bench.py and the
+multi-GPU driver use this module.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .engine import Hit, _raise_last
+
+
+def _check(rc):
+    if rc:
+        _raise_last()
+
+
+class Table(object):
+    """target sequences (bytes or str) + engine config -> device table"""
+
+    def __init__(self, seqs, **config):
+        L = _lib.lib()
+        self.seqs = [s.encode('latin-1') if isinstance(s, str) else bytes(s) for s in seqs]
+        n = len(self.seqs)
+        cfg = _lib.Config()
+        L.kvq_config_get(C.byref(cfg))
+        for k, v in config.items():
+            if k in ('Amin', 'Azero'):
+                v = (v.encode('latin-1') if isinstance(v, str) else v)[0]
+                v = v - 256 if v > 127 else v
+            setattr(cfg, k, v)
+        self.config = cfg
+        bufs = [C.create_string_buffer(s, len(s) + 1) for s in self.seqs]
+        arr = (C.c_char_p * max(1, n))(*[C.cast(b, C.c_char_p) for b in bufs])
+        lens = (C.c_int32 * max(1, n))(*[len(s) for s in self.seqs])
+        self.h = L.kvq_table_create(arr, lens, n, C.byref(cfg))
+        if not self.h:
+            _raise_last()
+        self.nseq = n
+        self.bases = L.kvq_table_bases(self.h)
+        self.counters_len = L.kvq_counters_len(self.h)
+        self.off_nseqhits = L.kvq_counters_off_nseqhits(self.h)
+        self.off_nseqbasehits = L.kvq_counters_off_nseqbasehits(self.h)
+        self.off_coverage = L.kvq_counters_off_coverage(self.h)
+        self.off_mutations = L.kvq_counters_off_mutations(self.h)
+        self.seq_offset = [L.kvq_table_seq_offset(self.h, i) for i in range(n + 1)]
+        self.seeded = [bool(L.kvq_table_seq_is_seeded(self.h, i)) for i in range(n)]
+        self.seed_k = L.kvq_table_seed_k(self.h)
+
+    def close(self):
+        if self.h:
+            _lib.lib().kvq_table_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def chunk_offsets(data):
+    """chunk cuts of fastq_read (workhorse.c:737-956) on an in-memory stream (numpy uint8 / bytes)"""
+    L = _lib.lib()
+    arr = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    cap = arr.nbytes // (512 * 1024) + 4
+    out = (C.c_int64 * (cap + 1))()
+    n = L.kvq_chunk_offsets(arr.ctypes.data if arr.nbytes else None, arr.nbytes, out, cap)
+    if n < 0:
+        raise RuntimeError('could find beginning of record')
+    return np.array(list(out)[:n + 1], dtype=np.int64)
+
+
+class Scanner(object):
+    """accumulates hits and counters over any number of batches"""
+
+    def __init__(self, table, counters_ptr=None):
+        self.table = table
+        self.h = _lib.lib().kvq_scan_create(table.h, counters_ptr)
+        if not self.h:
+            _raise_last()
+
+    def force_exhaustive(self, on=True):
+        _lib.lib().kvq_scan_force_exhaustive(self.h, 1 if on else 0)
+
+    def scan_device(self, d_ptr, nbytes, chunk_off, fpos_base=0):
+        co = np.ascontiguousarray(chunk_off, dtype=np.int64)
+        _check(_lib.lib().kvq_scan_device(self.h, d_ptr, nbytes, co.ctypes.data_as(C.POINTER(C.c_int64)), len(co) - 1, fpos_base))
+
+    def scan_host(self, data, chunk_off=None, fpos_base=0):
+        arr = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        co = chunk_offsets(arr) if chunk_off is None else np.ascontiguousarray(chunk_off, dtype=np.int64)
+        _check(_lib.lib().kvq_scan_host(self.h, arr.ctypes.data if arr.nbytes else None, arr.nbytes,
+                                        co.ctypes.data_as(C.POINTER(C.c_int64)), len(co) - 1, fpos_base))
+
+    def finish(self, hits=True):
+        """-> dict with 'hits', 'hitseqs' (bytes), 'stats', 'coverage', 'mutations', 'counters'"""
+        L = _lib.lib()
+        _check(L.kvq_scan_finish(self.h))
+        t = self.table
+        ctr = np.ctypeslib.as_array(L.kvq_scan_counters(self.h), shape=(t.counters_len,)).copy()
+        out = {'counters': ctr}
+        nh = L.kvq_scan_n_hits(self.h)
+        out['n_hits'] = nh
+        if hits:
+            a = [np.ctypeslib.as_array(f(self.h), shape=(nh,)).copy() if nh else np.zeros(0, dtype=np.int64)
+                 for f in (L.kvq_scan_hit_seq_nr, L.kvq_scan_hit_file_pos, L.kvq_scan_hit_seq_pos, L.kvq_scan_hit_length, L.kvq_scan_hit_readlength)]
+            out['hits'] = tuple(Hit(int(a[0][i]), int(a[1][i]), int(a[2][i]), int(a[3][i]), int(a[4][i])) for i in range(nh))
+            off = L.kvq_scan_hitseq_offsets(self.h)
+            blob = C.string_at(L.kvq_scan_hitseq_blob(self.h), off[nh]) if nh else b''
+            out['hitseqs'] = [blob[off[i]:off[i + 1]] for i in range(nh)]
+        longest = int(ctr[_lib.CTR_LONGEST]) - 1
+        parsed, total = L.kvq_scan_parsed(self.h), L.kvq_scan_total(self.h)
+        rls = ctr[_lib.CTR_READLENGTHS:_lib.CTR_READLENGTHS + _lib.MAX_READLENGTH]
+        out['stats'] = {
+            'readlengths': tuple(int(rls[i]) if i < _lib.MAX_READLENGTH else 0 for i in range(longest + 1)),
+            'progress': (C.c_float(C.c_float(min(parsed, total)).value / C.c_float(total).value).value if total > 0 else 0.0),
+            'nseqbasehits': tuple(int(x) for x in ctr[t.off_nseqbasehits:t.off_nseqbasehits + t.nseq]),
+            'nseqhits': tuple(int(x) for x in ctr[t.off_nseqhits:t.off_nseqhits + t.nseq]),
+            'parsed': parsed, 'total': total, 'sigints': 0, 'records_parsed': int(ctr[_lib.CTR_RECORDS]),
+        }
+        out['coverage'] = ctr[t.off_coverage:t.off_coverage + t.bases]
+        out['mutations'] = ctr[t.off_mutations:t.off_mutations + 6 * t.bases]
+        out['kernel_ms'] = L.kvq_scan_kernel_ms(self.h)
+        out['main_kernel_ms'] = L.kvq_scan_main_kernel_ms(self.h)
+        out['main_kernel_launches'] = L.kvq_scan_main_kernel_launches(self.h)
+        return out
+
+    def reset(self):
+        _check(_lib.lib().kvq_scan_reset(self.h))
+
+    def close(self):
+        if self.h:
+            _lib.lib().kvq_scan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer(object):
+    """a plain device allocation (hipMalloc) with host copies in and out"""
+
+    def __init__(self, nbytes):
+        self.nbytes = nbytes
+        self.ptr = _lib.lib().kvq_device_alloc(nbytes + 64)
+        if not self.ptr:
+            _raise_last()
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(_lib.lib().kvq_memcpy_h2d(self.ptr, arr.ctypes.data, arr.nbytes))
+
+    def download(self, nbytes=None, offset=0):
+        n = self.nbytes - offset if nbytes is None else nbytes
+        out = np.empty(n, dtype=np.uint8)
+        _check(_lib.lib().kvq_memcpy_d2h(out.ctypes.data, self.ptr + offset, n))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.lib().kvq_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

