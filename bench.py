@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""
+bench.py -- FastQ reads/sec scanned on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (engine.findseqs' scan: record split,
+quality trim, match against the MTBC-shaped table, hits + per-sequence counters
++ coverage/mutation counts back on the host) over one batch of synthetic FastQ
+that is already resident in HBM when the timed region starts.  Workload at N=1:
+BASELINE.json configs[2], 10 M x 150 bp reads vs the MTBC table (132 templates,
+both strands = 264 sequences) -- the configuration the north-star target is
+quoted on; it fits one GPU (3.25 GB).  With N > 1 every rank scans its own
+`--reads` records (weak scaling, reads shard without any data-path collective)
+and the counter arrays are summed with one RCCL all-reduce per step.
+
+    python bench.py                                   # N=1, 10 M reads
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+
+Prints ONE JSON line on rank 0 (contract in the task description): value =
+whole-job reads/s, roofline = algorithmic bytes (2L+25 per record) of the
+dominant kernel / its HIP-event time vs 8 TB/s HBM peak, cpu_baseline = the
+CPU engine timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def analytic_chunk_offsets(n_records, rb, L):
+    """chunk cuts of fastq_read (workhorse.c:737-956) for fixed-size synthetic
+    records: the cut falls on the last record whose '+' line starts inside the
+    1 MiB buffer (verified against the real chunker on a prefix, below)"""
+    total = n_records * rb
+    offs, cs = [0], 0
+    while True:
+        end = cs + (1 << 20)
+        if end > total or total - cs < (1 << 20):
+            break
+        if end == total:
+            pass
+        r = (end - 1 - (L + 22)) // rb
+        cut = r * rb
+        if cut <= cs:
+            raise RuntimeError('record larger than the scan buffer')
+        offs.append(cut)
+        cs = cut
+    offs.append(total)
+    return np.array(offs, dtype=np.int64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--reads', type=int, default=10_000_000, help='records per GPU')
+    ap.add_argument('--readlen', type=int, default=150)
+    ap.add_argument('--table', default='MTBC', choices=['MTBC', 'MTBC+barcodes'])
+    ap.add_argument('--table-scale', type=int, default=1)
+    ap.add_argument('--exhaustive', action='store_true', help='force the exhaustive kernel for every sequence')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of the CPU baseline sample')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    from kvarq_amd import _lib, scan, synth
+    L_ = _lib.lib()
+    if L_.kvq_device_count() <= 0:
+        raise SystemExit('bench.py needs an MI355X: libkvarq_hip has no CPU path')
+    if L_.kvq_set_device(local):
+        raise SystemExit('cannot select device %d' % local)
+
+    # ---- workload: resident in HBM before anything is timed -------------------
+    L = args.readlen
+    rb = synth.record_bytes(L)
+    n = args.reads
+    first = rank * n
+    g = synth.genome()
+    plus = synth.table(g, args.table, scale=args.table_scale)
+    seqs = synth.both_strands(plus)
+    cfg = dict(maxerrors=2, minoverlap=25, minreadlength=25, Amin='.')     # kvarq/config.py:2-10
+    d_genome = scan.DeviceBuffer(g.nbytes)
+    d_genome.upload(g)
+    d_data = scan.DeviceBuffer(n * rb)
+    if L_.kvq_synth_reads_device(d_data.ptr, first, n, L, synth.SEED, d_genome.ptr, g.nbytes):
+        raise SystemExit('synthetic generator failed: %s' % (_lib.last_error(),))
+    fpos0 = first * rb
+    offs = analytic_chunk_offsets(n, rb, L)
+    # the analytic cuts must be the real chunker's cuts (checked on a prefix of the device data)
+    k = min(len(offs) - 1, 8)
+    prefix = d_data.download(int(offs[k]))
+    real = scan.chunk_offsets(prefix) if offs[k] < n * rb else None
+    if real is not None and k > 1:
+        assert list(real[:k]) == list(offs[:k]), 'analytic chunk cuts disagree with the chunker'
+
+    # batches < 2 GiB, cut at chunk boundaries; the base pointer is aligned down to 16 bytes
+    batches, i = [], 0
+    while i < len(offs) - 1:
+        j = i
+        while j + 1 < len(offs) and offs[j + 1] - (offs[i] & ~15) < (1 << 30):
+            j += 1
+        base = int(offs[i]) & ~15
+        batches.append((base, int(offs[j]) - base, (offs[i:j + 1] - base).copy()))
+        i = j
+
+    table = scan.Table(seqs, **cfg)
+    if world > 1:
+        ctr = torch.zeros(table.counters_len, dtype=torch.int64, device='cuda')
+        scanner = scan.Scanner(table, ctr.data_ptr())
+    else:
+        ctr = None
+        scanner = scan.Scanner(table)
+    if args.exhaustive:
+        scanner.force_exhaustive(True)
+
+    def step():
+        scanner.reset()
+        for base, nbytes, co in batches:
+            scanner.scan_device(d_data.ptr + base, nbytes, co, fpos_base=fpos0 + base)
+        r = scanner.finish()
+        if world > 1:
+            longest = ctr[_lib.CTR_LONGEST].clone()
+            dist.all_reduce(ctr, op=dist.ReduceOp.SUM)                  # hit/coverage arrays over xGMI
+            dist.all_reduce(longest, op=dist.ReduceOp.MAX)
+            ctr[_lib.CTR_LONGEST] = longest
+        return r
+
+    def sync():
+        L_.kvq_device_synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    r = None
+    for _ in range(args.warmup):
+        r = step()
+    sync()
+    t0 = time.perf_counter()
+    kern_ms = main_ms = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        r = step()
+        kern_ms += r['kernel_ms']
+        main_ms += r['main_kernel_ms']
+        launches += r['main_kernel_launches']
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        total_records = int(ctr[_lib.CTR_RECORDS].item())
+        total_hits = int(ctr[_lib.CTR_HITS].item())
+    else:
+        total_records = r['stats']['records_parsed']
+        total_hits = r['n_hits']
+    assert r['stats']['records_parsed'] == n, 'records lost: %d of %d' % (r['stats']['records_parsed'], n)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n * args.steps / dt
+    main_avg_ms = main_ms / max(1, launches)
+    bytes_per_launch = n * rb / max(1, launches // args.steps) if launches else 0
+    achieved = (n * rb * args.steps) / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
+    out = {
+        'metric': 'fastq_reads_per_sec_scanned', 'value': value, 'unit': 'reads/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+        'config': {'workload': '%d x %d bp synthetic FastQ per GPU (%d B/record, resident in HBM) vs %s table '
+                               '(%d templates, both strands = %d sequences, %d bases); e=2, minoverlap=25, minreadlength=25, Amin=\'.\''
+                               % (n, L, rb, args.table, len(plus), len(seqs), sum(map(len, seqs))),
+                   'reads_per_gpu': n, 'readlen': L, 'table': args.table, 'table_scale': args.table_scale,
+                   'parallelism': 'read-shard x%d, all-reduce of counter arrays' % world if world > 1 else 'single GPU',
+                   'kernel_path': 'exhaustive' if args.exhaustive or not any(table.seeded) else
+                                  'seed-filter k=%d (%d of %d sequences)' % (table.seed_k, sum(table.seeded), table.nseq),
+                   'hits_per_step': total_hits, 'records_per_step': total_records},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'kernel': 'kvq_scan_seeded' if any(table.seeded) and not args.exhaustive else 'kvq_match_all',
+                     'launches_per_step': launches // max(1, args.steps), 'avg_launch_ms': main_avg_ms,
+                     'algorithmic_bytes_per_launch': bytes_per_launch,
+                     'all_kernels_ms_per_step': kern_ms / args.steps},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(g, seqs, cfg, L, rb, args.cpu_seconds)
+    print(json.dumps(out))
+    sys.stdout.flush()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(g, seqs, cfg, L, rb, seconds):
+    """the CPU engine on this host's cores, on a bounded sample of the same
+    workload: the reference's own engine (oracle/_ref) where it loads, else this
+    repo's C restatement of it (oracle/kvarq_oracle.c); both with one worker per core"""
+    from kvarq_amd import synth
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    probe = synth.reads(g, 0, 4000 * min(cores, 16), L)
+    t0 = time.perf_counter()
+    O.scan_memory(probe, seqs, nthreads=cores, **cfg)
+    rate = (probe.nbytes // rb) / (time.perf_counter() - t0)
+    n = int(max(20000, min(3_000_000, rate * seconds)))
+    data = synth.reads(g, 0, n, L)
+    t0 = time.perf_counter()
+    r = O.scan_memory(data, seqs, nthreads=cores, **cfg)
+    port = n / (time.perf_counter() - t0)
+    out = {'value': port, 'unit': 'reads/s', 'cores': cores, 'kind': 'port',
+           'sample': 'first %d records of the same synthetic stream (%d hits), %d worker threads' % (n, len(r['hits']), cores)}
+    try:
+        if O.ref_engine() is not None:
+            path = '/tmp/kvarq_bench_sample.fastq'
+            with open(path, 'wb') as f:
+                f.write(data.tobytes())
+            t0 = time.perf_counter()
+            rr = O.ref_findseqs(path, seqs, nthreads=cores, **cfg)
+            ref = n / (time.perf_counter() - t0)
+            os.remove(path)
+            assert len(rr['hits']) == len(r['hits'])
+            out.update({'value': ref, 'kind': 'reference', 'port_value': port})
+    except Exception as e:          # the reference build is optional on the GPU box
+        out['reference_error'] = str(e)[:200]
+    return out
+
+
+if __name__ == '__main__':
+    main()

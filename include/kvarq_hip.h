@@ -157,6 +157,10 @@ double  kvq_scan_main_kernel_ms(const kvq_scan *s);
 int64_t kvq_scan_main_kernel_launches(const kvq_scan *s);
 /* forget accumulated hits/counters/timers but keep buffers (bench steps) */
 int32_t kvq_scan_reset(kvq_scan *s);
+/* which kernels produced the result: bit 0 = the seed-filter kernel ran, bit 1 = the
+ * exhaustive kernels ran, bit 2 = a seed-filter pass was discarded (its speculated
+ * record split failed validation or a record outgrew the tile) and the data rescanned */
+int32_t kvq_scan_path(const kvq_scan *s);
 /* 0 = let the table decide, 1 = force the exhaustive kernel for every sequence */
 void    kvq_scan_force_exhaustive(kvq_scan *s, int32_t on);
 

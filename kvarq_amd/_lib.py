@@ -65,6 +65,7 @@ PROTOTYPES = {
     'kvq_scan_main_kernel_ms': (C.c_double, [vp]),
     'kvq_scan_main_kernel_launches': (i64, [vp]),
     'kvq_scan_reset': (i32, [vp]),
+    'kvq_scan_path': (i32, [vp]),
     'kvq_scan_force_exhaustive': (None, [vp, i32]),
     'kvq_findseqs': (vp, [P(cp), i32, P(cp), P(i32), i32]),
     'kvq_findseqs_free': (None, [vp]),

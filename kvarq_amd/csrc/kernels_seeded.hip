@@ -1,13 +1,773 @@
-// kvarq_amd/csrc/kernels_seeded.hip -- the seed-filter scan kernel (placeholder
-// until the fused kernel lands: every sequence goes to the exhaustive path).
+// kvarq_amd/csrc/kernels_seeded.hip -- the fused seed-filter scan: one pass over
+// the FastQ text does record split, quality trim, read-length histogram and
+// matching (workhorse.c:1010-1175) for every sequence that qualifies for seeding.
+//
+// Persistent workgroups (512 threads) walk 32 KiB tiles of the input:
+//   P0  tile (+4 KiB look-ahead) HBM -> registers -> LDS with 16-byte loads;
+//       newline flags are taken from the registers on the way
+//   P1  workgroup prefix sum -> sorted newline offsets in LDS
+//   P2  first record of the tile: exact for the first tile of a chunk, otherwise
+//       speculated from the text ("@" line followed two lines later by a "+"
+//       line) and verified after the kernel by kvq_validate_tiles against the
+//       exact count of newlines (four '\n' = one record, workhorse.c:1018-1034);
+//       any disagreement makes the host rescan with the exhaustive kernels
+//   P3  one wave per read: '@'/'+' checks (1037-1048), longest run of scores
+//       >= Amin via __ballot (1055-1068), LDS histogram (394-402); the read is
+//       2-bit packed with two ballots and every position's 8-mer is looked up
+//       in LDS-resident bitmaps; candidate (read, position) pairs go to an LDS queue
+//   P4  all lanes verify queued candidates: seed index -> (sequence, diagonal)
+//       -> byte-exact mismatch count under the class A/B/C rules (1112-1174)
+//       -> hits appended to the global arena (one atomic per wave)
+//
+// Seeding (pigeonhole, K = 8): an accepted alignment of length L >= (e+1)*K
+// with <= e mismatches has an exact K-mer block.  Alignments that start at the
+// read head (classes B, C "read in sequence") or end at the read tail (class A)
+// are found from 2(e+1) fixed read blocks in the index of ALL sequence
+// positions; a sequence contained in the read (class C "sequence in read") is
+// found from its e+1 ANCHOR blocks at any read position.  A diagonal found by
+// several seeds is emitted by the first live seed only (canonical order).
 #include "kvq_host.h"
 
-struct SeedIndex { int unused; };
+#include <algorithm>
+#include <string.h>
 
-SeedIndex *kvq_seed_index_build(kvq_table *t) { (void)t; return nullptr; }
-void kvq_seed_index_destroy(SeedIndex *ix) { delete ix; }
-int kvq_seeded_launch(kvq_scan *, const KvqParams &, const uint8_t *, int64_t, const uint32_t *, int64_t, int64_t, uint32_t)
+#define SK 8                       // seed length
+#define ST_TILE 32000u             // bytes a tile owns: 400 scan blocks of 80 bytes
+#define ST_OV 4160u                // look-ahead for the tile's last record (52 blocks)
+#define ST_PRE 80u                 // one (zeroed) block in front of the tile: buf[ST_PRE] = first owned byte
+#define ST_THREADS 512
+#define ST_WAVES (ST_THREADS / 64)
+#define ST_ROUNDS ((ST_TILE + ST_OV) / 16u / ST_THREADS + 1)    // 16-byte loads per thread
+#define ST_NLCAP 2048
+#define ST_RCAP 512
+#define ST_QCAP 1024            // candidates (read, position) per pass
+#define ST_Q2CAP 2048           // candidate x index entry pairs per pass
+#define ST_BLK 80u              // bytes one thread scans for newlines (LDS conflict-free stride)
+#define ST_BUF (ST_PRE + ST_TILE + ST_OV)
+
+// tile report word for kvq_validate_tiles
+#define TR_NONE 0xFFu              // no record starts in this tile
+#define TR_FLAG_FALLBACK 0x2000000u
+
+struct SeedTables {
+    const uint32_t *bm2;                      // 2 bits per 8-mer code: bit 0 = an anchor block, bit 1 = anywhere in a sequence
+    const uint32_t *start_anc, *start_all;    // CSR starts, 65537 entries
+    // entry: position in sequence (12) | sequence number (20) | table offset of the sequence (20) | its length (12)
+    const uint64_t *ent_anc, *ent_all;
+};
+
+struct SeedIndex {
+    DevBuf d_bm2, d_start_anc, d_start_all, d_ent_anc, d_ent_all;
+    DevBuf d_tile_chunk, d_tile_first, d_tile_report;
+    SeedTables dev;
+};
+
+__host__ __device__ static inline uint32_t code2_of(uint8_t c) { return (c >> 1) & 3u; }
+
+// 16-bit seed code of 8 bases: base t in bits 2t..2t+1 (rolls along a read with one shift)
+static uint32_t host_code8(const uint8_t *p)
 {
-    kvq_set_error(KVQ_ERR_RUNTIME, "seed-filter kernel not built");
-    return KVQ_ERR_RUNTIME;
+    uint32_t c = 0;
+    for (int i = 0; i < SK; i++) c |= code2_of(p[i]) << (2 * i);
+    return c;
+}
+
+SeedIndex *kvq_seed_index_build(kvq_table *t)
+{
+    const kvq_config &cfg = t->cfg;
+    t->seed_k = 0;
+    const int e = cfg.maxerrors;
+    if (e < 0 || e > 6) return nullptr;
+    const int need = (e + 1) * SK;
+    // every accepted alignment must be at least `need` long: class A/B overlaps
+    // are >= minoverlap, class C lengths are min(readlength, sequence length)
+    if (cfg.minoverlap < need || cfg.minreadlength < need) return nullptr;
+    if (cfg.Amin <= 13) return nullptr;          // the kernel relies on '\n' and '\r' closing every quality run (1058)
+    for (int s = 0; s < t->nseq; s++) {
+        const int len = t->h_off[s + 1] - t->h_off[s];
+        bool ok = len >= need && len <= 4095 && t->h_off[s] < (1 << 20) && s < (1 << 20);
+        for (int i = 0; ok && i < len; i++) {
+            const uint8_t c = t->h_tab[t->h_off[s] + i];
+            ok = (c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        }
+        if (ok) { t->seeded.push_back(s); t->is_seeded[s] = 1; }
+    }
+    if (t->seeded.empty()) return nullptr;
+    t->seed_k = SK;
+
+    std::vector<std::pair<uint32_t, uint64_t>> anc, all;       // (code, entry)
+    for (int s : t->seeded) {
+        const uint8_t *q = &t->h_tab[t->h_off[s]];
+        const int len = t->h_off[s + 1] - t->h_off[s];
+        const uint64_t hi = ((uint64_t)(uint32_t)t->h_off[s] << 32) | ((uint64_t)(uint32_t)len << 52) | ((uint64_t)(uint32_t)s << 12);
+        for (int j = 0; j <= e; j++) anc.emplace_back(host_code8(q + j * SK), hi | (uint64_t)(j * SK));
+        for (int p = 0; p + SK <= len; p++) all.emplace_back(host_code8(q + p), hi | (uint64_t)p);
+    }
+    SeedIndex *ix = new SeedIndex();
+    std::vector<uint32_t> bm2(4096, 0);
+    auto upload = [&](std::vector<std::pair<uint32_t, uint64_t>> &v, int bit, DevBuf &st, DevBuf &en) -> bool {
+        std::sort(v.begin(), v.end());
+        std::vector<uint32_t> start(65537, 0); std::vector<uint64_t> ent(v.size() + 1, 0);
+        for (size_t i = 0; i < v.size(); i++) { bm2[v[i].first >> 4] |= 1u << (2 * (v[i].first & 15) + bit); start[v[i].first + 1]++; ent[i] = v[i].second; }
+        for (int c = 0; c < 65536; c++) start[c + 1] += start[c];
+        return st.ensure(65537 * 4) == KVQ_OK && en.ensure(ent.size() * 8) == KVQ_OK &&
+               hipMemcpy(st.p, start.data(), 65537 * 4, hipMemcpyHostToDevice) == hipSuccess &&
+               hipMemcpy(en.p, ent.data(), ent.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!upload(anc, 0, ix->d_start_anc, ix->d_ent_anc) || !upload(all, 1, ix->d_start_all, ix->d_ent_all) ||
+        ix->d_bm2.ensure(16384) != KVQ_OK || hipMemcpy(ix->d_bm2.p, bm2.data(), 16384, hipMemcpyHostToDevice) != hipSuccess) {
+        if (!kvq_error_code()) kvq_set_error(KVQ_ERR_DEVICE, "uploading the seed index failed");
+        kvq_seed_index_destroy(ix);
+        return nullptr;
+    }
+    ix->dev.bm2 = ix->d_bm2.as<uint32_t>();
+    ix->dev.start_anc = ix->d_start_anc.as<uint32_t>(); ix->dev.start_all = ix->d_start_all.as<uint32_t>();
+    ix->dev.ent_anc = ix->d_ent_anc.as<uint64_t>(); ix->dev.ent_all = ix->d_ent_all.as<uint64_t>();
+    return ix;
+}
+
+void kvq_seed_index_destroy(SeedIndex *ix)
+{
+    if (!ix) return;
+    DevBuf *b[] = { &ix->d_bm2, &ix->d_start_anc, &ix->d_start_all, &ix->d_ent_anc, &ix->d_ent_all,
+                    &ix->d_tile_chunk, &ix->d_tile_first, &ix->d_tile_report };
+    for (DevBuf *x : b) x->release();
+    delete ix;
+}
+
+// ---------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------
+
+struct SeededLds {
+    uint8_t  buf[ST_BUF];                // buf[ST_PRE] = first byte the tile owns
+    uint16_t nl[ST_NLCAP];               // offsets into buf of every '\n', ascending
+    uint32_t bm2[4096];                  // 2 bits per 8-mer code (anchor / anywhere)
+    uint32_t hist[KVQ_RL_BINS];
+    uint2    q1[ST_QCAP];                // candidate: x = rec | pos << 16, y = code | kind << 16
+    uint32_t q2[ST_Q2CAP];               // work item: candidate << 22 | index entry
+    uint32_t rinfo[ST_RCAP];             // read offset in buf | rl << 16
+    uint32_t wtot[ST_WAVES];             // newlines per wave
+    uint32_t n_owned, qn, q2n, longest_p1, records, more, fallback;
+};
+
+// values that are the same in every lane (LDS reads at uniform addresses, wave
+// numbers) must be moved to scalar registers by hand: the compiler cannot know
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct TileGeo {
+    uint32_t a, b;          // chunk [a, b) in batch offsets
+    uint32_t t;             // tile number inside the chunk
+    uint32_t g0;            // batch offset of buf[ST_PRE]
+    uint32_t own_begin;     // first byte whose newlines this tile counts
+    uint32_t own_end;       // batch offset where ownership ends
+    uint32_t load_lo, load_hi, lds_lo;   // loaded byte range [load_lo, load_hi) lands at buf[lds_lo ...]
+};
+
+__device__ __forceinline__ TileGeo tile_geo(uint32_t g, const uint32_t *chunk_off, const uint32_t *tile_chunk, const uint32_t *tile_first)
+{
+    TileGeo J;
+    const uint32_t c = tile_chunk[g];
+    J.a = chunk_off[c]; J.b = chunk_off[c + 1];
+    J.t = g - tile_first[c];
+    J.g0 = (J.a & ~15u) + J.t * ST_TILE;
+    J.own_end = J.g0 + ST_TILE < J.b ? J.g0 + ST_TILE : J.b;
+    J.own_begin = J.t == 0 ? J.a : J.g0;
+    J.load_lo = J.g0;
+    J.load_hi = J.g0 + ST_TILE + ST_OV < J.b ? J.g0 + ST_TILE + ST_OV : J.b;
+    J.lds_lo = ST_PRE;
+    return J;
+}
+
+__device__ __forceinline__ uint32_t lds_code8(const SeededLds &S, uint32_t off)
+{
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < SK; i++) c |= code2_of(S.buf[off + i]) << (2 * i);
+    return c;
+}
+__device__ __forceinline__ uint32_t glb_code8(const uint8_t *x)
+{
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < SK; i++) c |= code2_of(x[i]) << (2 * i);
+    return c;
+}
+
+// 4 score bytes -> 4 bits, bit set = byte is good ((signed) c >= Amin, Amin in 14..127);
+// addk = (0x80 - Amin) * 0x01010101
+__device__ __forceinline__ uint32_t good4(uint32_t x, uint32_t addk)
+{
+    const uint32_t gf = ((x & 0x7F7F7F7Fu) + addk) & ~x & 0x80808080u;    // 0x80 per good byte
+    return (gf * 0x00204081u) >> 28;                                       // bits 7,15,23,31 -> 0..3
+}
+
+// longest run of ones in the low n (1..64) bits of m, first one if several: length, start
+__device__ __forceinline__ void longest_run64(uint64_t m, int n, int &len, int &start)
+{
+    const uint64_t r1 = m & (m << 1), r2 = r1 & (r1 << 2), r3 = r2 & (r2 << 4), r4 = r3 & (r3 << 8), r5 = r4 & (r4 << 16);
+    // E = end positions of runs of length >= L; grow L by binary descent
+    uint64_t E = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    int L = 0; uint64_t T;
+    T = E & r5;        if (T) { E = T; L = 32; }
+    T = E & (r4 << L); if (T) { E = T; L += 16; }
+    T = E & (r3 << L); if (T) { E = T; L += 8; }
+    T = E & (r2 << L); if (T) { E = T; L += 4; }
+    T = E & (r1 << L); if (T) { E = T; L += 2; }
+    T = E & (m << L);  if (T) { E = T; L += 1; }
+    len = L;
+    start = L ? (__ffsll((long long)E) - 1) - L + 1 : 0;
+}
+
+// longest-run summary of a stretch of score bytes; merge is associative (left, right)
+struct Seg { int len, pre, suf, best, bstart, beg; };
+
+__device__ __forceinline__ Seg seg_merge(const Seg &A, const Seg &B)
+{
+    Seg R;
+    R.beg = A.beg; R.len = A.len + B.len;
+    R.pre = (A.pre == A.len) ? A.len + B.pre : A.pre;
+    R.suf = (B.suf == B.len) ? B.len + A.suf : B.suf;
+    R.best = A.best; R.bstart = A.bstart;                       // the first of equally long runs wins (1062)
+    const int cross = A.suf + B.pre;
+    if (cross > R.best) { R.best = cross; R.bstart = A.beg + A.len - A.suf; }
+    if (B.best > R.best) { R.best = B.best; R.bstart = B.bstart; }
+    return R;
+}
+
+// is the seed (read block at rp, sequence block at sq) live: equal 2-bit codes
+__device__ __forceinline__ bool seed_live(const SeededLds &S, uint32_t roff, int rl, int rp, const uint8_t *seq, int seql, int sq)
+{
+    if (rp < 0 || rp + SK > rl || sq < 0 || sq + SK > seql) return false;
+    return lds_code8(S, roff + (uint32_t)rp) == glb_code8(seq + sq);
+}
+
+// number of differing bytes of two dwords
+__device__ __forceinline__ int diff_bytes(uint32_t x, uint32_t y)
+{
+    const uint32_t v = x ^ y;
+    return __popc((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u);
+}
+
+// One work item = one (candidate, index entry) pair = one diagonal of one read
+// against one sequence: byte-exact check under the reference's loop bounds and
+// emission of its hits.  Must be called by every lane of the wave.
+__device__ __forceinline__ void verify_item(const KvqParams &P, const SeededLds &S, bool active, uint32_t rec, int p,
+                                            uint32_t kind, uint64_t en, int64_t tile_fpos)
+{
+    bool hitAB = false, hitC = false;
+    int s = 0, rl = 0, lenAB = 0, lenC = 0, sposAB = 0, sposC = 0; uint32_t keyAB = 0, keyC = 0;
+    int64_t fpos = 0;
+    if (active) {
+        const uint32_t ri = S.rinfo[rec];
+        const uint32_t roff = ri & 0xFFFFu; rl = (int)(ri >> 16);
+        fpos = tile_fpos + (int64_t)roff - (int64_t)ST_PRE;
+        const int q = (int)(en & 4095u);
+        s = (int)((en >> 12) & 0xFFFFFu);
+        const uint8_t *seq = P.tab + (uint32_t)((en >> 32) & 0xFFFFFu);
+        const int seql = (int)(en >> 52);
+        const int mo = P.minoverlap, me = P.maxerrors;
+        const int d = q - p;                             // sequence index = read index + d
+        const int a = d < 0 ? -d : 0;
+        const int L = (rl < seql - d ? rl : seql - d) - a;
+        // which reference loops visit this diagonal
+        bool canAB = false, canC = false;
+        const bool guard = rl > mo && seql > mo;
+        if (d < 0) {
+            const int i = -d;
+            if (i <= rl - seql) { canC = true; lenC = seql; sposC = -i; keyC = (2u << 30) | (uint32_t)i; }              // 1147
+            else if (guard && i <= rl - mo) { canAB = true; lenAB = rl - i; sposAB = -i; keyAB = (0u << 30) | (uint32_t)(rl - mo - i); }   // 1116
+        } else if (d == 0) {
+            canC = true; lenC = rl > seql ? seql : rl; sposC = 0; keyC = 2u << 30;                                         // 1147 / 1163
+        } else {
+            const int i = d;
+            if (guard && i <= seql - mo && i >= seql - rl) { canAB = true; lenAB = seql - i; sposAB = i; keyAB = (1u << 30) | (uint32_t)(seql - mo - i); }   // 1130
+            if (rl <= seql && i <= seql - rl) { canC = true; lenC = rl; sposC = i; keyC = (2u << 30) | (uint32_t)i; }       // 1163
+        }
+        if ((canAB || canC) && L > 0) {
+            int mism = 0, j = 0;
+            const uint32_t x = roff + (uint32_t)a; const uint8_t *y = seq + a + d;
+            for (; j + 4 <= L && mism <= me; j += 4) {
+                uint32_t rw, sw;
+                __builtin_memcpy(&rw, &S.buf[x + j], 4); __builtin_memcpy(&sw, y + j, 4);
+                mism += diff_bytes(rw, sw);
+            }
+            for (; j < L && mism <= me; j++) mism += (S.buf[x + j] != y[j]);
+            if (mism <= me) {
+                // canonical discoverer: no live seed earlier in the order
+                // [ALL-index read blocks by position] then [ANCHOR blocks by number]
+                bool earlier = false;
+                for (int jj = 0; jj <= me && !earlier; jj++) {
+                    const int ph = jj * SK, pt = rl - (jj + 1) * SK;
+                    if (ph + SK <= rl && (kind == 0u || ph < p)) earlier = seed_live(S, roff, rl, ph, seq, seql, ph + d);
+                    if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live(S, roff, rl, pt, seq, seql, pt + d);
+                }
+                if (kind == 0u)
+                    for (int jj = 0; jj * SK < q && !earlier; jj++) earlier = seed_live(S, roff, rl, jj * SK - d, seq, seql, jj * SK);
+                if (!earlier) { hitAB = canAB; hitC = canC; }
+            }
+        }
+    }
+    kvq_emit(P, hitAB, fpos, s, sposAB, lenAB, rl, keyAB);
+    kvq_emit(P, hitC, fpos, s, sposC, lenC, rl, keyC);
+}
+
+__device__ __forceinline__ uint32_t bits8_at(uint32_t w0, uint32_t w1, uint32_t w2, int lane)
+{
+    // bits lane .. lane+7 of the 96-bit string w0 | w1 << 32 | w2 << 64
+    const uint32_t lo = lane < 32 ? w0 : w1, hi = lane < 32 ? w1 : w2;
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)lane & 31u) & 0xFFu;
+}
+
+extern "C" __global__ void __launch_bounds__(ST_THREADS, 4)
+kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int64_t fpos_base,
+                const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ tile_chunk,
+                const uint32_t *__restrict__ tile_first, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg)
+{
+    extern __shared__ __align__(16) uint8_t lds_raw[];
+    SeededLds &S = *reinterpret_cast<SeededLds *>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = rfl((uint32_t)tid >> 6);
+    // diagnostic build only (dbg & 16): cycles of wave 0 per phase, summed over tiles
+    unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_t = 0;
+#define STAMP(i) do { if (dbg & 16u) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
+
+    for (int i = tid; i < 4096; i += ST_THREADS) S.bm2[i] = X.bm2[i];
+    for (int i = tid; i < KVQ_RL_BINS; i += ST_THREADS) S.hist[i] = 0;
+    if (tid == 0) { S.longest_p1 = 0; S.records = 0; }
+    if (tid < (int)(ST_PRE / 4)) reinterpret_cast<uint32_t *>(S.buf)[tid] = 0;      // the block in front of the tile never holds text
+
+    // the tile's text travels HBM -> registers (one tile ahead) -> LDS
+    uint4 pre[ST_ROUNDS];
+    if (blockIdx.x < ntiles) {
+        const TileGeo J = tile_geo(blockIdx.x, chunk_off, tile_chunk, tile_first);
+#pragma unroll
+        for (int r = 0; r < (int)ST_ROUNDS; r++) {
+            const uint32_t gp = J.load_lo + (uint32_t)(r * ST_THREADS + tid) * 16u;
+            pre[r] = gp < J.load_hi ? *reinterpret_cast<const uint4 *>(data + gp) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
+        const TileGeo J = tile_geo(g, chunk_off, tile_chunk, tile_first);
+        if (dbg & 16u) stamp_t = __builtin_amdgcn_s_memtime();
+
+        // ---- P0: registers -> LDS (coalesced order); the next tile's loads go out ----
+        // bytes in front of the chunk start and behind the loaded text are zeroed here (at most
+        // two vectors per tile), so that the scan below needs no masks
+#pragma unroll
+        for (int r = 0; r < (int)ST_ROUNDS; r++) {
+            const uint32_t off = (uint32_t)(r * ST_THREADS + tid) * 16u;          // relative to g0
+            const uint32_t gp = J.g0 + off;
+            if (gp < J.load_hi) {
+                uint4 v = pre[r];
+                if (gp < J.own_begin || gp + 16u > J.load_hi) {
+                    uint32_t x[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const uint32_t keep = kvq_range_flags(gp + 4u * d, J.own_begin, J.load_hi);   // 0x80 per byte inside
+                        x[d] &= (keep >> 7) * 0xFFu;
+                    }
+                    v = make_uint4(x[0], x[1], x[2], x[3]);
+                }
+                *reinterpret_cast<uint4 *>(&S.buf[ST_PRE + off]) = v;
+            }
+        }
+        if (g + gridDim.x < ntiles) {
+            const TileGeo N = tile_geo(g + gridDim.x, chunk_off, tile_chunk, tile_first);
+#pragma unroll
+            for (int r = 0; r < (int)ST_ROUNDS; r++) {
+                const uint32_t gp = N.load_lo + (uint32_t)(r * ST_THREADS + tid) * 16u;
+                pre[r] = gp < N.load_hi ? *reinterpret_cast<const uint4 *>(data + gp) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (tid == 0) { S.n_owned = 0; S.fallback = 0; }
+        __syncthreads();
+        STAMP(0);
+
+        // ---- P1: every thread scans ST_BLK contiguous bytes of the tile for '\n' ----
+        // (80-byte stride: the five ds_read_b128 of a wave are bank-conflict free; ownership
+        // ends on a block boundary, so a block is owned entirely or not at all)
+        const uint32_t own_end_l = J.own_end - J.g0 + ST_PRE;              // ownership ends here
+        const uint32_t end_l = J.load_hi - J.g0 + ST_PRE;                  // end of the loaded text
+        uint32_t fl[ST_BLK / 4]; uint32_t cnt = 0;
+        const uint32_t blk = (uint32_t)tid * ST_BLK;
+#pragma unroll
+        for (int v = 0; v < (int)(ST_BLK / 16); v++) {
+            if (blk + 16u * v < end_l) {                                    // vectors behind the text hold stale bytes
+                const uint4 w = *reinterpret_cast<const uint4 *>(&S.buf[blk + 16u * v]);
+                fl[4 * v + 0] = kvq_nl_flags(w.x); fl[4 * v + 1] = kvq_nl_flags(w.y);
+                fl[4 * v + 2] = kvq_nl_flags(w.z); fl[4 * v + 3] = kvq_nl_flags(w.w);
+            } else { fl[4 * v + 0] = fl[4 * v + 1] = fl[4 * v + 2] = fl[4 * v + 3] = 0; }
+        }
+#pragma unroll
+        for (int d = 0; d < (int)(ST_BLK / 4); d++) cnt += __popc(fl[d]);
+        const uint32_t cnt_owned = blk < own_end_l ? cnt : 0u;            // own_end_l is a block boundary or the end of the text
+        const uint32_t incl = kvq_wave_incl_scan(cnt);
+        if (lane == 63) S.wtot[wave] = incl;
+        {
+            // owned newlines: one LDS atomic per wave
+            uint32_t o = cnt_owned;
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) o += __shfl_xor(o, dd, 64);
+            if (lane == 0 && o) atomicAdd(&S.n_owned, o);
+        }
+        if (tid == 0) { S.qn = 0; S.q2n = 0; }
+        __syncthreads();
+        STAMP(1);
+        uint32_t n_all = 0;
+        {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int w = 0; w < ST_WAVES; w++) { const uint32_t t = S.wtot[w]; if (w == (int)wave) mine = n_all; n_all += t; }
+            uint32_t n = mine + incl - cnt;
+            if (cnt) {
+#pragma unroll
+                for (int v = 0; v < (int)(ST_BLK / 16); v++) {
+                    // 16 flag bits of this vector, then its (few) set bits
+                    uint32_t m16 = ((fl[4 * v] * 0x00204081u) >> 28) | (((fl[4 * v + 1] * 0x00204081u) >> 28) << 4) |
+                                   (((fl[4 * v + 2] * 0x00204081u) >> 28) << 8) | (((fl[4 * v + 3] * 0x00204081u) >> 28) << 12);
+                    if ((fl[4 * v] | fl[4 * v + 1] | fl[4 * v + 2] | fl[4 * v + 3]) == 0u) m16 = 0;
+                    while (m16) {
+                        const int bit = __ffs((int)m16) - 1; m16 &= m16 - 1u;
+                        if (n < ST_NLCAP) S.nl[n] = (uint16_t)(blk + 16u * v + (uint32_t)bit);
+                        n++;
+                    }
+                }
+            }
+        }
+        n_all = rfl(n_all);
+        __syncthreads();
+        STAMP(2);
+
+        // ---- P2 (every wave, redundantly): which records does this tile own? ----
+        uint32_t nrec = 0, jn = TR_NONE;
+        {
+            const uint32_t n_nl = n_all < ST_NLCAP ? n_all : ST_NLCAP;
+            const uint32_t n_owned = rfl(S.n_owned);
+            uint32_t fallback = n_all > ST_NLCAP ? 1u : 0u;
+            // a record belongs to the tile that owns the '\n' in front of it (the chunk's
+            // first record to tile 0), also when its first byte is the next tile's first
+            if (J.t == 0) jn = 0;                                            // chunk start: exact
+            else {
+                // lane m (m >= 1): does the line behind the tile's m-th newline start with '@'
+                // and the line two further on with '+'?
+                const uint32_t m = (uint32_t)lane;
+                bool ok = false;
+                if (m >= 1 && m <= 8 && m <= n_owned && m + 2 <= n_nl) {
+                    const uint32_t ls0 = (uint32_t)S.nl[m - 1] + 1u;
+                    const uint32_t ls2 = (uint32_t)S.nl[m + 1] + 1u;
+                    ok = ls0 < end_l && ls2 < end_l && S.buf[ls0] == '@' && S.buf[ls2] == '+';
+                }
+                const uint64_t mk = __ballot(ok);
+                if (mk) jn = (uint32_t)(__ffsll((long long)mk) - 1);
+            }
+            // records owned by the tile start behind newline jn + 4k (k >= 0) while that newline is owned
+            if (jn != TR_NONE) {
+                if (jn <= n_owned) nrec = (n_owned - jn) / 4u + 1u;
+                // keep only records whose four newlines were loaded; a missing one means
+                // chunk end (partial record, dropped: 1033) or a record longer than the look-ahead
+                if (nrec > 0 && jn + 4u * nrec > n_nl) {
+                    const uint32_t fit = n_nl >= jn ? (n_nl - jn) / 4u : 0u;
+                    if (J.load_hi < J.b || n_all > ST_NLCAP) fallback = 1u;
+                    nrec = fit;
+                }
+                if (nrec > ST_RCAP) { nrec = ST_RCAP; fallback = 1u; }
+            }
+            if (tid == 0) {
+                tile_report[g] = (n_owned & 0xFFFFu) | ((jn & 0xFFu) << 16) | (fallback ? TR_FLAG_FALLBACK : 0u);
+                S.records += nrec;
+            }
+        }
+
+        STAMP(3);
+        // ---- P3 / P4 passes: reads -> candidates, then candidates -> hits ----
+        // G lanes share one read (G = 4 for 150 bp reads): each lane scans a contiguous
+        // slice of the score line / of the bases serially, so that one wave instruction
+        // advances 64/G reads and hardly anything runs on the scalar unit
+        const int64_t tile_fpos = fpos_base + (int64_t)J.g0;
+        uint32_t lg = 0;
+        while (lg < 6u && (2u << lg) * nrec <= ST_THREADS) lg++;
+        const uint32_t G = 1u << lg, RP = ST_THREADS >> lg;
+        const uint32_t gl = (uint32_t)tid & (G - 1u), gr = (uint32_t)tid >> lg;
+        for (uint32_t pass0 = 0; pass0 < nrec; pass0 += RP) {
+            const uint32_t k = pass0 + gr;
+            const bool have = k < nrec;
+            uint32_t roff = 0; int rl = 0;
+            if (have) {
+                const uint32_t m = jn + 4u * k;
+                const uint32_t rstart = m == 0 ? ST_PRE + (J.a - (J.a & ~15u)) : (uint32_t)S.nl[m - 1] + 1u;
+                const uint32_t n0 = S.nl[m], n1 = S.nl[m + 1], n2 = S.nl[m + 2], n3 = S.nl[m + 3];
+                const uint32_t sread = n0 + 1u, plus = n1 + 1u, sscore = n2 + 1u;
+                if (gl == 0) {
+                    const uint32_t c0 = S.buf[rstart], cp = S.buf[plus];
+                    if (c0 != '@') atomicMin(P.err, ((unsigned long long)(tile_fpos + rstart - ST_PRE) << 16) | (0ull << 8) | c0);
+                    else if (cp != '+') atomicMin(P.err, ((unsigned long long)(tile_fpos + plus - ST_PRE) << 16) | (1ull << 8) | cp);
+                }
+                // quality trim (1055-1068): this lane's slice of the score line -> bitmask of good
+                // bytes (SWAR, a dword at a time) -> longest run by shifts, no per-byte branching
+                const int Q = (int)(n3 - sscore);                   // the closing '\n' is implied
+                const int per = (Q + (int)G - 1) >> lg;
+                Seg sg; sg.beg = (int)gl * per; if (sg.beg > Q) sg.beg = Q;
+                int s1 = sg.beg + per; if (s1 > Q) s1 = Q;
+                sg.len = 0; sg.pre = 0; sg.suf = 0; sg.best = 0; sg.bstart = sg.beg;
+                {
+                    const uint32_t addk = (uint32_t)(0x80 - P.amin) * 0x01010101u;
+                    for (int c0 = sg.beg; c0 < s1; c0 += 64) {             // one round unless a slice exceeds 64 bytes
+                        const int n = s1 - c0 < 64 ? s1 - c0 : 64;
+                        const uint32_t abs0 = sscore + (uint32_t)c0, abs1 = abs0 + (uint32_t)n;
+                        uint32_t w = abs0 & ~3u;
+                        const int lead = (int)(abs0 - w);                  // bytes of the first dword in front of the slice
+                        // dwords w, w+4, ... cover the slice; they are fetched four at a time (bytes
+                        // behind the slice are masked off below, the buffer has slack behind its end)
+                        uint64_t m = 0;
+                        int sh = -lead;
+                        for (; w < abs1; w += 16u, sh += 16) {
+                            uint32_t q[4];
+#pragma unroll
+                            for (int t = 0; t < 4; t++) q[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
+                            uint32_t g16 = 0;
+#pragma unroll
+                            for (int t = 0; t < 4; t++) g16 |= good4(q[t], addk) << (4 * t);
+                            m |= sh >= 0 ? ((uint64_t)g16 << sh) : ((uint64_t)g16 >> (-sh));
+                        }
+                        if (n < 64) m &= (1ull << n) - 1ull;
+                        Seg sub; sub.beg = c0; sub.len = n;
+                        const uint64_t inv = ~m;
+                        sub.pre = inv ? __ffsll((long long)inv) - 1 : 64; if (sub.pre > n) sub.pre = n;
+                        const uint64_t top = ~(m << (64 - n));             // leading ones of the n-bit mask = trailing run
+                        sub.suf = top ? __clzll((long long)top) : 64; if (sub.suf > n) sub.suf = n;
+                        int bl, bs; longest_run64(m, n, bl, bs);
+                        sub.best = bl; sub.bstart = c0 + bs;
+                        sg = (c0 == sg.beg) ? sub : seg_merge(sg, sub);
+                    }
+                }
+                // ordered tree merge over the G lanes of the read
+                for (uint32_t d = 1; d < G; d <<= 1) {
+                    Seg B;
+                    B.len = __shfl_xor(sg.len, (int)d, 64); B.pre = __shfl_xor(sg.pre, (int)d, 64); B.suf = __shfl_xor(sg.suf, (int)d, 64);
+                    B.best = __shfl_xor(sg.best, (int)d, 64); B.bstart = __shfl_xor(sg.bstart, (int)d, 64); B.beg = 0;
+                    if ((gl & d) == 0) sg = seg_merge(sg, B);
+                }
+                rl = __shfl(sg.best, lane & ~(int)(G - 1u), 64);
+                roff = sread + (uint32_t)__shfl(sg.bstart, lane & ~(int)(G - 1u), 64);                 // 1070
+                if (gl == 0) {
+                    if (rl < KVQ_RL_BINS) atomicAdd(&S.hist[rl], 1u);                                 // 394-402
+                    atomicMax(&S.longest_p1, (uint32_t)(rl + 1));
+                    S.rinfo[k] = roff | ((uint32_t)rl << 16);
+                }
+            }
+            STAMP(4);
+            // seed filter: this lane's slice of the read's 8-mer positions.  Bases come in aligned
+            // dwords; every base rolls the 2-bit code and looks it up in the 2-bit bitmap; the
+            // answers pile up in registers (2 bits per base slot) and are sorted out after the loop
+            int p0 = 0, p1 = 0;
+            if (have && rl >= P.minreadlength && !(dbg & 2u)) {                                        // 1100
+                const int NP = rl - (SK - 1);
+                const int per = (NP + (int)G - 1) >> lg;
+                p0 = (int)gl * per; if (p0 > NP) p0 = NP;
+                p1 = p0 + per; if (p1 > NP) p1 = NP;
+            }
+            for (int c0 = p0; __any(c0 < p1); c0 += 48) {                  // one round unless a slice exceeds 48 positions
+                const bool act = c0 < p1;
+                const int c1 = act ? (p1 - c0 < 48 ? p1 : c0 + 48) : c0;
+                // base slot u = 4k + b of dword k; slot u finishes the 8-mer at position c0 + u - (skip + 7)
+                const uint32_t w0 = (roff + (uint32_t)c0) & ~3u;
+                const int skip7 = (int)(roff + (uint32_t)c0 - w0) + (SK - 1);
+                const int nd = act ? ((c1 - c0) + skip7 + 3) >> 2 : 0;      // dwords to stream (<= 15)
+                uint64_t acc = 0, acc_lo = 0;
+                uint32_t code = 0;
+                uint32_t x = *reinterpret_cast<const uint32_t *>(&S.buf[w0]);
+                int ndmax = nd;
+#pragma unroll
+                for (int dd = 32; dd >= 1; dd >>= 1) { const int o = __shfl_xor(ndmax, dd, 64); ndmax = o > ndmax ? o : ndmax; }
+                ndmax = (ndmax + 1) & ~1;                                   // dwords are streamed in pairs
+                uint32_t x1 = *reinterpret_cast<const uint32_t *>(&S.buf[w0 + 4u]);
+                for (int kd = 0; kd < ndmax; kd += 2) {
+                    // next pair first, so that its latency hides behind this pair's work
+                    const uint32_t wn = w0 + 4u * (uint32_t)(kd + 2);
+                    const uint32_t wq = wn + 8u <= ST_BUF ? wn : w0;
+                    uint2 xn;
+                    xn.x = *reinterpret_cast<const uint32_t *>(&S.buf[wq]); xn.y = *reinterpret_cast<const uint32_t *>(&S.buf[wq + 4u]);
+                    uint32_t cds[8], wv[8];
+#pragma unroll
+                    for (int bb = 0; bb < 8; bb++) {
+                        const uint32_t c2 = ((bb < 4 ? x : x1) >> (8 * (bb & 3) + 1)) & 3u;
+                        code = (code >> 2) | (c2 << 14);
+                        cds[bb] = code;
+                    }
+#pragma unroll
+                    for (int bb = 0; bb < 8; bb++) wv[bb] = S.bm2[cds[bb] >> 4];
+                    uint32_t nib = 0;
+#pragma unroll
+                    for (int bb = 0; bb < 8; bb++) nib |= ((wv[bb] >> ((cds[bb] & 15u) << 1)) & 3u) << (2 * bb);
+                    if (kd == 8) { acc_lo = acc; acc = 0; }
+                    acc |= (uint64_t)nib << (8 * (kd & 7));
+                    x = xn.x; x1 = xn.y;
+                }
+                if (ndmax <= 8) { acc_lo = acc; acc = 0; }
+                // valid slots: skip7 <= u < skip7 + (c1 - c0); bit 0 of a pair = anchor hit, bit 1 = hit anywhere.
+                // Keep anchor hits of valid slots and "anywhere" hits of the read's fixed head / tail blocks only
+                const int ulo = skip7, uhi = skip7 + (c1 - c0);
+                for (int half = 0; half < 2; half++) {
+                    uint64_t h = half ? acc : acc_lo;
+                    int lo = ulo - 32 * half, hi = uhi - 32 * half;
+                    lo = lo < 0 ? 0 : (lo > 32 ? 32 : lo); hi = hi < 0 ? 0 : (hi > 32 ? 32 : hi);
+                    uint64_t keep = 0;
+                    if (hi > lo) {
+                        const uint64_t upto_hi = hi >= 32 ? ~0ull : ((1ull << (2 * hi)) - 1ull);
+                        keep = (upto_hi & ~((1ull << (2 * lo)) - 1ull)) & 0x5555555555555555ull;
+                        for (int j = 0; j <= P.maxerrors; j++) {
+                            const int uh = j * SK - c0 + skip7 - 32 * half;                 // head block j
+                            const int ut = rl - (j + 1) * SK - c0 + skip7 - 32 * half;      // tail block j
+                            if (uh >= lo && uh < hi) keep |= 2ull << (2 * uh);
+                            if (ut >= lo && ut < hi) keep |= 2ull << (2 * ut);
+                        }
+                    }
+                    h &= keep;
+                    while (__any(act && h != 0)) {
+                        if (act && h) {
+                            const int bit = __ffsll((long long)h) - 1; h &= h - 1ull;
+                            const int pp = c0 + (bit >> 1) + 32 * half - skip7;
+                            const uint32_t kind = (uint32_t)(bit & 1);
+                            const uint32_t cd = lds_code8(S, roff + (uint32_t)pp);
+                            const uint32_t idx = atomicAdd(&S.qn, 1u);
+                            if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)pp << 16), cd | (kind << 16));
+                            else S.fallback = 1u;                                                      // queue full: the tile is rescanned exhaustively
+                        }
+                    }
+                }
+            }
+            STAMP(5);
+            __syncthreads();
+            STAMP(6);
+
+            // ---- P4a: one candidate per lane: index range -> (candidate, entry) work items ----
+            const uint32_t qall = rfl(S.qn);
+            const uint32_t qn = qall < ST_QCAP ? qall : ST_QCAP;
+            if (!(dbg & 1u))
+            for (uint32_t q0 = wave * 64u; q0 < qn; q0 += ST_THREADS) {
+                const uint32_t qi = q0 + lane;
+                uint32_t e0 = 0, ne = 0;
+                if (qi < qn) {
+                    const uint2 cd = S.q1[qi];
+                    const uint32_t *st = (cd.y >> 16) ? X.start_all : X.start_anc;
+                    e0 = st[cd.y & 0xFFFFu]; ne = st[(cd.y & 0xFFFFu) + 1u] - e0;
+                }
+                const uint32_t inc = kvq_wave_incl_scan(ne);
+                uint32_t base = 0;
+                if (lane == 63 && inc) base = atomicAdd(&S.q2n, inc);
+                base = __shfl(base, 63, 64) + inc - ne;
+                for (uint32_t j = 0; j < ne; j++)
+                    if (base + j < ST_Q2CAP) S.q2[base + j] = (qi << 22) | (e0 + j);
+            }
+            __syncthreads();
+
+            // ---- P4b: one work item per lane ----
+            {
+                const uint32_t q2all = rfl(S.q2n);
+                const uint32_t q2n = q2all < ST_Q2CAP ? q2all : ST_Q2CAP;
+                if (q2all > ST_Q2CAP && tid == 0) S.fallback = 1u;
+                if (!(dbg & 1u))
+                for (uint32_t i0 = wave * 64u; i0 < q2n; i0 += ST_THREADS) {
+                    const uint32_t ii = i0 + lane;
+                    const bool active = ii < q2n;
+                    uint32_t rec = 0, kind = 0; int p = 0; uint64_t en = 0;
+                    if (active) {
+                        const uint32_t it = S.q2[ii];
+                        const uint2 cd = S.q1[it >> 22];
+                        rec = cd.x & 0xFFFFu; p = (int)(cd.x >> 16); kind = cd.y >> 16;
+                        en = (kind ? X.ent_all : X.ent_anc)[it & 0x3FFFFFu];
+                    }
+                    verify_item(P, S, active, rec, p, kind, en, tile_fpos);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) { S.qn = 0; S.q2n = 0; }
+            __syncthreads();
+            STAMP(7);
+        }
+        if (tid == 0 && S.fallback) atomicOr(&tile_report[g], TR_FLAG_FALLBACK);
+        __syncthreads();
+    }
+
+    if ((dbg & 16u) && tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&P.ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
+    // ---- flush per-workgroup counters ----
+    for (int i = tid; i < KVQ_RL_BINS; i += ST_THREADS)
+        if (S.hist[i]) atomicAdd(&P.ctr[KVQ_CTR_RL_ + i], (unsigned long long)S.hist[i]);
+    if (tid == 0) {
+        if (S.longest_p1) atomicMax(&P.ctr[KVQ_CTR_LONGEST_], (unsigned long long)S.longest_p1);
+        if (S.records) atomicAdd(&P.ctr[KVQ_CTR_RECORDS_], (unsigned long long)S.records);
+    }
+}
+
+// one thread per chunk: replay the tile reports against the exact newline
+// count; any tile whose speculated first record is not the one the count gives
+// sets *spec_fail (the host then rescans with the exhaustive kernels)
+extern "C" __global__ void __launch_bounds__(256)
+kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_report,
+                   unsigned int *__restrict__ spec_fail)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    uint32_t seen = 0;                         // newlines of the chunk in front of the tile
+    bool bad = false;
+    for (uint32_t g = tile_first[c]; g < tile_first[c + 1]; g++) {
+        const uint32_t rep = tile_report[g];
+        const uint32_t n_owned = rep & 0xFFFFu, jn = (rep >> 16) & 0xFFu;
+        if (rep & TR_FLAG_FALLBACK) bad = true;
+        // the first record this tile owns starts behind its newline number `want`
+        // (tile 0: the chunk start itself)
+        const uint32_t want = g == tile_first[c] ? 0u : 4u - (seen & 3u);
+        if (want <= n_owned) { if (jn != want) bad = true; }
+        else if (jn != TR_NONE) bad = true;
+        seen += n_owned;
+    }
+    if (bad) atomicOr(spec_fail, 1u);
+}
+
+// ---------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------
+
+int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
+                      const uint32_t *d_chunk_off, int64_t nchunks, int64_t fpos_base, uint32_t max_chunk_bytes)
+{
+    (void)nbytes; (void)max_chunk_bytes;
+    SeedIndex *ix = s->t->index;
+    // tiles per chunk from the host copy of the chunk offsets (the last batch pushed)
+    const std::vector<int64_t> &co = s->cur_chunk_off;
+    std::vector<uint32_t> first((size_t)nchunks + 1), chunk_of;
+    uint64_t nt = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
+        const uint32_t n = b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + ST_TILE - 1) / ST_TILE) : 0u;
+        first[c] = (uint32_t)nt;
+        for (uint32_t k = 0; k < n; k++) chunk_of.push_back((uint32_t)c);
+        nt += n;
+    }
+    first[nchunks] = (uint32_t)nt;
+    if (nt == 0) return KVQ_OK;
+    int rc;
+    if ((rc = ix->d_tile_chunk.ensure(chunk_of.size() * 4))) return rc;
+    if ((rc = ix->d_tile_first.ensure(first.size() * 4))) return rc;
+    if ((rc = ix->d_tile_report.ensure((size_t)nt * 4))) return rc;
+    KVQ_HIP(hipMemcpyAsync(ix->d_tile_chunk.p, chunk_of.data(), chunk_of.size() * 4, hipMemcpyHostToDevice, s->stream));
+    KVQ_HIP(hipMemcpyAsync(ix->d_tile_first.p, first.data(), first.size() * 4, hipMemcpyHostToDevice, s->stream));
+    KVQ_HIP(hipStreamSynchronize(s->stream));          // the host vectors die at return
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        KVQ_HIP(hipFuncSetAttribute((const void *)kvq_scan_seeded, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
+        attr_set = true;
+    }
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, 512);
+    hipLaunchKernelGGL(kvq_scan_seeded, dim3(grid), dim3(ST_THREADS), sizeof(SeededLds), s->stream, P, ix->dev, d_data, fpos_base,
+                       d_chunk_off, ix->d_tile_chunk.as<uint32_t>(), ix->d_tile_first.as<uint32_t>(), (uint32_t)nt,
+                       ix->d_tile_report.as<uint32_t>(), (uint32_t)(getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0));
+    hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
+                       ix->d_tile_first.as<uint32_t>(), ix->d_tile_report.as<uint32_t>(), s->d_spec_fail);
+    KVQ_HIP(hipGetLastError());
+    return KVQ_OK;
 }

@@ -13,7 +13,6 @@
 
 int64_t kvq_tail_record(const uint8_t *buf, int64_t n);
 int kvq_scan_finish_internal(kvq_scan *s);
-#define KVQ_NEED_RESCAN (-2)
 
 // ---------------------------------------------------------------------------
 // live state shared with engine.stats()/engine.stop()

@@ -64,7 +64,10 @@ struct kvq_scan {
     // hit arena
     DevBuf d_arena, d_blob, d_small;   // d_small: arena_n, batch range words, blob_n, err
     uint32_t arena_cap = 0; uint64_t blob_cap = 0;
-    unsigned int *d_arena_n = nullptr, *d_range = nullptr; unsigned long long *d_blob_n = nullptr, *d_err = nullptr;
+    unsigned int *d_arena_n = nullptr, *d_range = nullptr, *d_spec_fail = nullptr; unsigned long long *d_blob_n = nullptr, *d_err = nullptr;
+    int path_bits = 0;
+    bool seeded_off = false;             // a speculated record split failed validation: exhaustive kernels only
+    std::vector<int64_t> cur_chunk_off;  // chunk offsets of the batch being enqueued
     // staging for host batches
     DevBuf d_stage;
     // replay list (device batches) + bookkeeping

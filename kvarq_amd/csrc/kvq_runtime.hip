@@ -9,6 +9,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+// internal: arena too small or speculation failed; the caller must rescan
+#define KVQ_NEED_RESCAN (-2)
+
 // ---------------------------------------------------------------------------
 // error state and config
 // ---------------------------------------------------------------------------
@@ -150,7 +153,7 @@ extern "C" int64_t kvq_table_seq_offset(const kvq_table *t, int32_t s) { return 
 // ---------------------------------------------------------------------------
 
 #define KVQ_MAX_BATCHES 65536
-// d_small layout (bytes): [0] arena_n u32, [8] blob_n u64, [16] err u64, [64 ..) range words u32 x (KVQ_MAX_BATCHES+1)
+// d_small layout (bytes): [0] arena_n u32, [8] blob_n u64, [16] err u64, [24] spec_fail u32, [64 ..) range words u32 x (KVQ_MAX_BATCHES+1)
 static const size_t SMALL_BYTES = 64 + 4 * (KVQ_MAX_BATCHES + 1);
 
 static int reset_device_state(kvq_scan *s)
@@ -193,6 +196,7 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     s->d_arena_n = (unsigned int *)s->d_small.p;
     s->d_blob_n = (unsigned long long *)((char *)s->d_small.p + 8);
     s->d_err = (unsigned long long *)((char *)s->d_small.p + 16);
+    s->d_spec_fail = (unsigned int *)((char *)s->d_small.p + 24);
     s->d_range = (unsigned int *)((char *)s->d_small.p + 64);
     if (ensure_arena(s, 1u << 20, 64ull << 20) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     if (reset_device_state(s) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
@@ -220,6 +224,7 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     delete s;
 }
 
+extern "C" int32_t kvq_scan_path(const kvq_scan *s) { return s->path_bits; }
 extern "C" void kvq_scan_force_exhaustive(kvq_scan *s, int32_t on) { s->force_exhaustive = on != 0; }
 
 extern "C" int32_t kvq_scan_reset(kvq_scan *s)
@@ -228,8 +233,8 @@ extern "C" int32_t kvq_scan_reset(kvq_scan *s)
     KVQ_HIP(hipStreamSynchronize(s->stream));
     drop_events(s);
     s->batches.clear(); s->host_batches = false; s->records = 0; s->parsed = 0; s->total = 0;
-    s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false;
-    return reset_device_state(s);
+    s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->path_bits &= 4;
+    return reset_device_state(s);      // seeded_off is sticky for the life of the scan object
 }
 
 static KvqParams make_params(const kvq_scan *s)
@@ -267,7 +272,8 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     if (((uintptr_t)d_data & 15u) != 0) { kvq_set_error(KVQ_ERR_RUNTIME, "device buffer must be 16-byte aligned"); return KVQ_ERR_RUNTIME; }
 
     KvqParams P = make_params(s);
-    const bool use_seeded = t->index && !t->seeded.empty() && !s->force_exhaustive;
+    const bool use_seeded = t->index && !t->seeded.empty() && !s->force_exhaustive && !s->seeded_off;
+    s->cur_chunk_off.assign(chunk_off, chunk_off + nchunks + 1);
     const std::vector<int32_t> *exh = &t->exhaustive;
     const int32_t *d_exh = t->d_exh.as<int32_t>();
     std::vector<int32_t> all;
@@ -304,11 +310,12 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
         KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream));
         if ((rc = kvq_seeded_launch(s, P, d_data, nbytes, s->d_chunk_off.as<uint32_t>(), nchunks, fpos_base, maxchunk))) return rc;
         KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
-        s->main_launches++;
+        s->main_launches++; s->path_bits |= 1;
         hist_done = true;
     }
 
     if (!hist_done || n_exh > 0) {
+        if (n_exh > 0) s->path_bits |= 2;
         if ((rc = s->d_seg_base.ensure(sb.size() * 4))) return rc;
         if ((rc = s->d_seg_cnt.ensure((size_t)(segs + 1) * 4))) return rc;
         if ((rc = s->d_chunk_nrec.ensure((size_t)(nchunks + 1) * 4))) return rc;
@@ -389,16 +396,19 @@ extern "C" int32_t kvq_scan_host(kvq_scan *s, const void *h_data, int64_t nbytes
     return run_batch(s, s->d_stage.as<uint8_t>(), nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1);
 }
 
-// internal: arena too small; the caller must rescan (sizes are in the scan object)
-#define KVQ_NEED_RESCAN (-2)
-
 static int finish_once(kvq_scan *s)
 {
     KVQ_HIP(hipStreamSynchronize(s->stream));
-    unsigned char small[24];
-    KVQ_HIP(hipMemcpy(small, s->d_small.p, 24, hipMemcpyDeviceToHost));
-    unsigned int n_hits; unsigned long long blob_n, err;
-    memcpy(&n_hits, small, 4); memcpy(&blob_n, small + 8, 8); memcpy(&err, small + 16, 8);
+    unsigned char small[32];
+    KVQ_HIP(hipMemcpy(small, s->d_small.p, 32, hipMemcpyDeviceToHost));
+    unsigned int n_hits, spec_fail; unsigned long long blob_n, err;
+    memcpy(&n_hits, small, 4); memcpy(&blob_n, small + 8, 8); memcpy(&err, small + 16, 8); memcpy(&spec_fail, small + 24, 4);
+    if (spec_fail && !s->seeded_off) {
+        // a tile's speculated record split disagreed with the newline count (or a record
+        // outgrew the tile look-ahead): nothing of this pass is trusted, scan again exactly
+        s->seeded_off = true; s->path_bits = 4;
+        return KVQ_NEED_RESCAN;
+    }
     if (err != ~0ull) {
         // first malformed record in stream order (workhorse.c:1037-1048)
         const long fpos = (long)(err >> 16); const int kind = (int)((err >> 8) & 0xFF); const int ch = (int)(err & 0xFF);

@@ -128,6 +128,8 @@ class Scanner(object):
         out['kernel_ms'] = L.kvq_scan_kernel_ms(self.h)
         out['main_kernel_ms'] = L.kvq_scan_main_kernel_ms(self.h)
         out['main_kernel_launches'] = L.kvq_scan_main_kernel_launches(self.h)
+        path = L.kvq_scan_path(self.h)
+        out['path'] = {'seeded': bool(path & 1), 'exhaustive': bool(path & 2), 'rescanned': bool(path & 4)}
         return out
 
     def reset(self):

@@ -169,3 +169,69 @@ def test_concurrent_findseqs_is_refused_and_stop_works(tmp_path):
     th.join()
     assert 'r' in out and out['r']['stats']['records_parsed'] <= 9000 * 40
     assert refused or out['r']['stats']['records_parsed'] == 9000 * 40
+
+
+def test_seeded_and_exhaustive_kernels_agree_and_paths_are_as_expected(tmp_path):
+    """the seed-filter kernel against the exhaustive kernels on the same device data,
+    and which of them served each case"""
+    want_path = {
+        'synth20k_mtbc': dict(seeded=True, exhaustive=False, rescanned=False),
+        'spoligo_5k': dict(seeded=True, exhaustive=False, rescanned=False),
+        'multichunk': dict(seeded=True, exhaustive=True, rescanned=False),      # N-holding sequence -> exhaustive
+        'quirk_e2': dict(seeded=True, exhaustive=False, rescanned=False),
+        'long_reads': dict(seeded=True, exhaustive=False, rescanned=False),     # 11 kB in all: one tile holds it
+        'ragged_crlf': dict(seeded=False, exhaustive=True, rescanned=False),    # e=3, minoverlap 12: not seedable
+        'findseqs': dict(seeded=False, exhaustive=True, rescanned=False),
+    }
+    want_path['long_reads_x12'] = dict(seeded=False, exhaustive=True, rescanned=True)   # 6 kB records straddle the tile look-ahead
+    for name, wp in want_path.items():
+        case = cases.by_name()[name.replace('_x12', '')]
+        files = case.materialize(tmp_path)
+        data = np.frombuffer(b''.join(open(f, 'rb').read() for f in files[:1]) * (12 if name.endswith('_x12') else 1), dtype=np.uint8)
+        t = scan.Table(case.seq_bytes(), **case.config)
+        res = []
+        for force in (False, True):
+            s = scan.Scanner(t)
+            s.force_exhaustive(force)
+            s.scan_host(data)
+            res.append(s.finish())
+            s.close()
+        a, b = res
+        assert a['path'] == wp, (name, a['path'])
+        assert b['path']['seeded'] is False
+        assert a['hits'] == b['hits'] and a['hitseqs'] == b['hitseqs'], name
+        assert (a['counters'] == b['counters']).all(), name
+        t.close()
+
+
+def test_speculation_failure_falls_back_to_the_exact_split():
+    """a FastQ whose base lines may start with '@' or '+' defeats the text heuristic;
+    the validation pass must notice and the rescan must give the reference's answer"""
+    import random
+    rng = random.Random(99)
+    target = cases.QUIRK_SEQ
+    recs = []
+    for i in range(4000):
+        bases = cases.randseq(rng, rng.randint(60, 200))
+        if i % 7 == 0:
+            bases = '@' + bases[1:]
+        if i % 11 == 0:
+            bases = '+' + bases[1:]
+        if i % 5 == 0:
+            at = rng.randint(1, len(bases) - 1)
+            bases = (bases[:at] + target)[:230]
+        q = ''.join(rng.choice('@+IIII') for _ in bases)
+        recs.append(cases.rec('r%d' % i, bases, q))
+    data = np.frombuffer(b''.join(recs), dtype=np.uint8)
+    seqs = synth.both_strands([target.encode()])
+    cfg = dict(cases.PRODUCT, Amin='!')
+    o = O.scan_memory(data, seqs, fold=True, **dict(cfg, nthreads=4))
+    t = scan.Table(seqs, **cfg)
+    s = scan.Scanner(t)
+    s.scan_host(data)
+    r = s.finish()
+    assert tuple(r['hits']) == tuple(o['hits']) and r['hitseqs'] == o['hitseqs']
+    assert r['stats']['readlengths'] == o['stats']['readlengths'] and r['stats']['records_parsed'] == 4000
+    assert r['coverage'].tolist() == o['coverage']
+    assert len(o['hits']) > 100
+    s.close(); t.close()

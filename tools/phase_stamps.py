@@ -1,0 +1,20 @@
+import sys, os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import numpy as np
+from kvarq_amd import _lib, scan, synth
+g = synth.genome(); seqs = synth.both_strands(synth.table(g))
+n, L = 2500000, 150; rb = synth.record_bytes(L)
+dg = scan.DeviceBuffer(g.nbytes); dg.upload(g); dd = scan.DeviceBuffer(n*rb)
+_lib.lib().kvq_synth_reads_device(dd.ptr, 0, n, L, synth.SEED, dg.ptr, g.nbytes)
+import importlib.util
+spec = importlib.util.spec_from_file_location('bench', os.path.join(os.environ.get('GRAFT_REPO_ROOT','/root/repo'),'bench.py')); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+co = b.analytic_chunk_offsets(n, rb, L)
+t = scan.Table(seqs, maxerrors=2, minoverlap=25, minreadlength=25, Amin='.')
+s = scan.Scanner(t)
+for rep in range(2):
+    s.reset(); s.scan_device(dd.ptr, n*rb, co); r = s.finish(hits=False)
+c = r['counters'][4+900:4+908].astype(np.float64)
+names = ['P0 store+bar', 'P1a scan+bar', 'P1b write+bar', 'P2', 'P3 desc+trim', 'P3 filter', 'bar after P3', 'P4a+P4b+bars']
+tot = c.sum()
+print('main kernel ms', r['main_kernel_ms'], 'tiles/WG', (n*rb/32000)/512)
+for nm, v in zip(names, c): print('%-16s %6.1f%%  %8.0f cycles/tile' % (nm, 100*v/tot, v/512/((n*rb/32000)/512)))
