@@ -137,7 +137,7 @@ def main():
         scanner.reset()
         for base, nbytes, co in batches:
             scanner.scan_device(d_data.ptr + base, nbytes, co, fpos_base=fpos0 + base)
-        r = scanner.finish()
+        r = scanner.finish(hits=False)      # hits, hit bytes and counters are on the host (C arrays); no Python tuples here
         if world > 1:
             longest = ctr[_lib.CTR_LONGEST].clone()
             dist.all_reduce(ctr, op=dist.ReduceOp.SUM)                  # hit/coverage arrays over xGMI

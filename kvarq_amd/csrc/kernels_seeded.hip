@@ -58,7 +58,6 @@ struct SeedTables {
 
 struct SeedIndex {
     DevBuf d_bm2, d_start_anc, d_start_all, d_ent_anc, d_ent_all;
-    DevBuf d_tile_chunk, d_tile_first, d_tile_report;
     SeedTables dev;
 };
 
@@ -129,8 +128,7 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
 void kvq_seed_index_destroy(SeedIndex *ix)
 {
     if (!ix) return;
-    DevBuf *b[] = { &ix->d_bm2, &ix->d_start_anc, &ix->d_start_all, &ix->d_ent_anc, &ix->d_ent_all,
-                    &ix->d_tile_chunk, &ix->d_tile_first, &ix->d_tile_report };
+    DevBuf *b[] = { &ix->d_bm2, &ix->d_start_anc, &ix->d_start_all, &ix->d_ent_anc, &ix->d_ent_all };
     for (DevBuf *x : b) x->release();
     delete ix;
 }
@@ -731,43 +729,57 @@ kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, co
 // launch
 // ---------------------------------------------------------------------------
 
+// one thread per chunk: tile_chunk[g] = chunk of tile g
+extern "C" __global__ void __launch_bounds__(256)
+kvq_expand_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, uint32_t *__restrict__ tile_chunk)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    for (uint32_t g = tile_first[c]; g < tile_first[c + 1]; g++) tile_chunk[g] = c;
+}
+
 int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
                       const uint32_t *d_chunk_off, int64_t nchunks, int64_t fpos_base, uint32_t max_chunk_bytes)
 {
     (void)nbytes; (void)max_chunk_bytes;
     SeedIndex *ix = s->t->index;
-    // tiles per chunk from the host copy of the chunk offsets (the last batch pushed)
+    // tiles per chunk; the tables live in the scan's pool so that nothing here waits for the GPU
     const std::vector<int64_t> &co = s->cur_chunk_off;
-    std::vector<uint32_t> first((size_t)nchunks + 1), chunk_of;
     uint64_t nt = 0;
     for (int64_t c = 0; c < nchunks; c++) {
         const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
-        const uint32_t n = b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + ST_TILE - 1) / ST_TILE) : 0u;
-        first[c] = (uint32_t)nt;
-        for (uint32_t k = 0; k < n; k++) chunk_of.push_back((uint32_t)c);
-        nt += n;
+        nt += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + ST_TILE - 1) / ST_TILE) : 0u;
     }
-    first[nchunks] = (uint32_t)nt;
     if (nt == 0) return KVQ_OK;
     int rc;
-    if ((rc = ix->d_tile_chunk.ensure(chunk_of.size() * 4))) return rc;
-    if ((rc = ix->d_tile_first.ensure(first.size() * 4))) return rc;
-    if ((rc = ix->d_tile_report.ensure((size_t)nt * 4))) return rc;
-    KVQ_HIP(hipMemcpyAsync(ix->d_tile_chunk.p, chunk_of.data(), chunk_of.size() * 4, hipMemcpyHostToDevice, s->stream));
-    KVQ_HIP(hipMemcpyAsync(ix->d_tile_first.p, first.data(), first.size() * 4, hipMemcpyHostToDevice, s->stream));
-    KVQ_HIP(hipStreamSynchronize(s->stream));          // the host vectors die at return
+    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 4 + (size_t)nt * 8 + 4096, s->stream))) return rc;
+    const size_t first_at = s->pool.take(((size_t)nchunks + 1) * 4);
+    const size_t chunk_at = s->pool.take((size_t)nt * 4), report_at = s->pool.take((size_t)nt * 4);
+    uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
+    uint64_t acc = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
+        first[c] = (uint32_t)acc;
+        acc += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + ST_TILE - 1) / ST_TILE) : 0u;
+    }
+    first[nchunks] = (uint32_t)acc;
+    uint32_t *d_first = reinterpret_cast<uint32_t *>(s->pool.d + first_at);
+    uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
+    uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
+    KVQ_HIP(hipMemcpyAsync(d_first, first, ((size_t)nchunks + 1) * 4, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_first, d_tchunk);
 
     static bool attr_set = false;
     if (!attr_set) {
         KVQ_HIP(hipFuncSetAttribute((const void *)kvq_scan_seeded, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
         attr_set = true;
     }
+    static const uint32_t dbg = (uint32_t)(getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, 512);
     hipLaunchKernelGGL(kvq_scan_seeded, dim3(grid), dim3(ST_THREADS), sizeof(SeededLds), s->stream, P, ix->dev, d_data, fpos_base,
-                       d_chunk_off, ix->d_tile_chunk.as<uint32_t>(), ix->d_tile_first.as<uint32_t>(), (uint32_t)nt,
-                       ix->d_tile_report.as<uint32_t>(), (uint32_t)(getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0));
+                       d_chunk_off, d_tchunk, d_first, (uint32_t)nt, d_report, dbg);
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
-                       ix->d_tile_first.as<uint32_t>(), ix->d_tile_report.as<uint32_t>(), s->d_spec_fail);
+                       d_first, d_report, s->cur_fail);
     KVQ_HIP(hipGetLastError());
     return KVQ_OK;
 }

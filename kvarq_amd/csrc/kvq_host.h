@@ -32,6 +32,15 @@ struct DevBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
+// per-batch tables (chunk offsets, tile maps): pinned host memory mirrored by device
+// memory, bump-allocated so that a batch can be enqueued without waiting for the previous one
+struct TablePool {
+    uint8_t *h = nullptr, *d = nullptr; size_t cap = 0, used = 0;
+    int reserve(size_t bytes, hipStream_t stream);   // makes room (may synchronise the stream when growing)
+    size_t take(size_t bytes) { const size_t at = used; used += (bytes + 255) & ~(size_t)255; return at; }
+    void release();
+};
+
 struct kvq_table {
     kvq_config cfg;
     int32_t nseq = 0;
@@ -50,6 +59,8 @@ struct kvq_table {
 struct Batch {
     const uint8_t *d_data; int64_t nbytes; int64_t fpos_base;
     std::vector<int64_t> chunk_off;
+    bool redone = false;      // its seed-filter pass failed validation; an exhaustive redo batch follows
+    bool is_redo = false;     // this batch is such a redo
 };
 
 struct kvq_scan {
@@ -64,10 +75,11 @@ struct kvq_scan {
     // hit arena
     DevBuf d_arena, d_blob, d_small;   // d_small: arena_n, batch range words, blob_n, err
     uint32_t arena_cap = 0; uint64_t blob_cap = 0;
-    unsigned int *d_arena_n = nullptr, *d_range = nullptr, *d_spec_fail = nullptr; unsigned long long *d_blob_n = nullptr, *d_err = nullptr;
+    unsigned int *d_arena_n = nullptr, *d_range = nullptr, *d_fail = nullptr, *cur_fail = nullptr;
+    unsigned long long *d_blob_n = nullptr, *d_err = nullptr, *d_err_stage = nullptr, *d_stage_ctr = nullptr;
     int path_bits = 0;
-    bool seeded_off = false;             // a speculated record split failed validation: exhaustive kernels only
     std::vector<int64_t> cur_chunk_off;  // chunk offsets of the batch being enqueued
+    TablePool pool;
     // staging for host batches
     DevBuf d_stage;
     // replay list (device batches) + bookkeeping

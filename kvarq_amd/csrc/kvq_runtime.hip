@@ -62,6 +62,29 @@ int DevBuf::ensure(size_t n)
 }
 void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 
+int TablePool::reserve(size_t bytes, hipStream_t stream)
+{
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    if (used + bytes <= cap) return KVQ_OK;
+    // grow: earlier batches may still read the old blocks, so wait for them first
+    if (stream) KVQ_HIP(hipStreamSynchronize(stream));
+    const size_t want = std::max<size_t>(2 * cap, std::max<size_t>(bytes, (size_t)8 << 20));
+    release();
+    if (hipHostMalloc((void **)&h, want, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d, want) != hipSuccess) {
+        release();
+        kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate %zu bytes of batch tables", want);
+        return KVQ_ERR_MEMORY;
+    }
+    cap = want; used = 0;
+    return KVQ_OK;
+}
+void TablePool::release()
+{
+    if (h) (void)hipHostFree(h);
+    if (d) (void)hipFree(d);
+    h = d = nullptr; cap = used = 0;
+}
+
 extern "C" int32_t kvq_device_count(void)
 {
     int n = 0;
@@ -153,13 +176,38 @@ extern "C" int64_t kvq_table_seq_offset(const kvq_table *t, int32_t s) { return 
 // ---------------------------------------------------------------------------
 
 #define KVQ_MAX_BATCHES 65536
-// d_small layout (bytes): [0] arena_n u32, [8] blob_n u64, [16] err u64, [24] spec_fail u32, [64 ..) range words u32 x (KVQ_MAX_BATCHES+1)
-static const size_t SMALL_BYTES = 64 + 4 * (KVQ_MAX_BATCHES + 1);
+// d_small layout (bytes): [0] arena_n u32, [8] blob_n u64, [16] err u64, [24] err of the batch in flight u64,
+// [64 ..) range words u32 x (KVQ_MAX_BATCHES+1), then per-batch "speculation failed" flags u32 x KVQ_MAX_BATCHES,
+// then the staging counters of the batch in flight (records, longest, read-length histogram)
+#define KVQ_STAGE_SLOTS (KVQ_CTR_RL_ + KVQ_RL_BINS)
+static const size_t SMALL_RANGE = 64, SMALL_FAIL = SMALL_RANGE + 4 * (KVQ_MAX_BATCHES + 1),
+                    SMALL_STAGE = (SMALL_FAIL + 4 * KVQ_MAX_BATCHES + 255) & ~(size_t)255,
+                    SMALL_BYTES = SMALL_STAGE + 8 * KVQ_STAGE_SLOTS;
+
+// after the kernels of one batch: merge the seed-filter kernel's staged counters and error
+// into the scan's, or -- when its speculated record split failed validation -- forget
+// everything the batch appended to the hit arena (the host rescans it exhaustively)
+extern "C" __global__ void __launch_bounds__(256)
+kvq_commit_batch(unsigned long long *stage, unsigned long long *ctr, unsigned long long *err_stage, unsigned long long *err,
+                 const unsigned int *fail, unsigned int *arena_n, const unsigned int *range_begin)
+{
+    const bool bad = *fail != 0u;
+    for (int i = threadIdx.x; i < KVQ_STAGE_SLOTS; i += blockDim.x) {
+        const unsigned long long v = stage[i];
+        if (v && !bad) { if (i == KVQ_CTR_LONGEST_) atomicMax(&ctr[i], v); else atomicAdd(&ctr[i], v); }
+        stage[i] = 0;
+    }
+    if (threadIdx.x == 0) {
+        if (bad) *arena_n = *range_begin;
+        else if (*err_stage != ~0ull) atomicMin(err, *err_stage);
+        *err_stage = ~0ull;
+    }
+}
 
 static int reset_device_state(kvq_scan *s)
 {
     KVQ_HIP(hipMemsetAsync(s->d_small.p, 0, SMALL_BYTES, s->stream));
-    KVQ_HIP(hipMemsetAsync(s->d_err, 0xFF, 8, s->stream));
+    KVQ_HIP(hipMemsetAsync(s->d_err, 0xFF, 16, s->stream));       // err and the staged err
     KVQ_HIP(hipMemsetAsync(s->d_ctr, 0, (size_t)s->t->ctr_len * 8, s->stream));
     return KVQ_OK;
 }
@@ -196,8 +244,10 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     s->d_arena_n = (unsigned int *)s->d_small.p;
     s->d_blob_n = (unsigned long long *)((char *)s->d_small.p + 8);
     s->d_err = (unsigned long long *)((char *)s->d_small.p + 16);
-    s->d_spec_fail = (unsigned int *)((char *)s->d_small.p + 24);
-    s->d_range = (unsigned int *)((char *)s->d_small.p + 64);
+    s->d_err_stage = (unsigned long long *)((char *)s->d_small.p + 24);
+    s->d_range = (unsigned int *)((char *)s->d_small.p + SMALL_RANGE);
+    s->d_fail = (unsigned int *)((char *)s->d_small.p + SMALL_FAIL);
+    s->d_stage_ctr = (unsigned long long *)((char *)s->d_small.p + SMALL_STAGE);
     if (ensure_arena(s, 1u << 20, 64ull << 20) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     if (reset_device_state(s) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     s->h_ctr.assign((size_t)t->ctr_len, 0);
@@ -220,6 +270,7 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     DevBuf *bufs[] = { &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
                        &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
     for (DevBuf *b : bufs) b->release();
+    s->pool.release();
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -233,8 +284,9 @@ extern "C" int32_t kvq_scan_reset(kvq_scan *s)
     KVQ_HIP(hipStreamSynchronize(s->stream));
     drop_events(s);
     s->batches.clear(); s->host_batches = false; s->records = 0; s->parsed = 0; s->total = 0;
-    s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->path_bits &= 4;
-    return reset_device_state(s);      // seeded_off is sticky for the life of the scan object
+    s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->path_bits = 0;
+    s->pool.used = 0;
+    return reset_device_state(s);
 }
 
 static KvqParams make_params(const kvq_scan *s)
@@ -263,7 +315,7 @@ static int new_event_pair(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v)
 // enqueue every kernel of one batch.  The exhaustive path needs one host
 // round trip (records per chunk) to size its record arrays.
 static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks,
-                     int64_t fpos_base, size_t batch_no)
+                     int64_t fpos_base, size_t batch_no, bool exhaustive_only)
 {
     const kvq_table *t = s->t;
     if (nbytes <= 0 || nchunks <= 0) return KVQ_OK;
@@ -272,7 +324,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     if (((uintptr_t)d_data & 15u) != 0) { kvq_set_error(KVQ_ERR_RUNTIME, "device buffer must be 16-byte aligned"); return KVQ_ERR_RUNTIME; }
 
     KvqParams P = make_params(s);
-    const bool use_seeded = t->index && !t->seeded.empty() && !s->force_exhaustive && !s->seeded_off;
+    const bool use_seeded = t->index && !t->seeded.empty() && !s->force_exhaustive && !exhaustive_only;
     s->cur_chunk_off.assign(chunk_off, chunk_off + nchunks + 1);
     const std::vector<int32_t> *exh = &t->exhaustive;
     const int32_t *d_exh = t->d_exh.as<int32_t>();
@@ -280,8 +332,13 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     if (!use_seeded) { d_exh = t->d_all.as<int32_t>(); }
     const int32_t n_exh = use_seeded ? (int32_t)exh->size() : t->nseq;
 
-    // chunk table
-    std::vector<uint32_t> co((size_t)nchunks + 1), sb((size_t)nchunks + 1);
+    // chunk table: written into the pinned half of the pool, copied to its device half (async)
+    int rc;
+    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 4 + 4096, s->stream))) return rc;
+    const size_t co_at = s->pool.take(((size_t)nchunks + 1) * 4);
+    uint32_t *co = reinterpret_cast<uint32_t *>(s->pool.h + co_at);
+    const uint32_t *d_co = reinterpret_cast<const uint32_t *>(s->pool.d + co_at);
+    std::vector<uint32_t> sb((size_t)nchunks + 1);
     uint32_t maxseg = 0, maxchunk = 0; uint64_t segs = 0;
     for (int64_t c = 0; c <= nchunks; c++) {
         if (chunk_off[c] < 0 || chunk_off[c] > nbytes || (c && chunk_off[c] < chunk_off[c - 1])) {
@@ -296,10 +353,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
         maxseg = std::max(maxseg, n); maxchunk = std::max(maxchunk, b - a);
     }
     sb[nchunks] = (uint32_t)segs;
-    int rc;
-    if ((rc = s->d_chunk_off.ensure(co.size() * 4))) return rc;
-    KVQ_HIP(hipMemcpyAsync(s->d_chunk_off.p, co.data(), co.size() * 4, hipMemcpyHostToDevice, s->stream));
-    KVQ_HIP(hipStreamSynchronize(s->stream));      // co is a local: the copy must be done before it dies
+    KVQ_HIP(hipMemcpyAsync(s->pool.d + co_at, co, ((size_t)nchunks + 1) * 4, hipMemcpyHostToDevice, s->stream));
 
     if ((rc = new_event_pair(s->ev_all))) return rc;
     KVQ_HIP(hipEventRecord(s->ev_all.back().first, s->stream));
@@ -308,7 +362,10 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     if (use_seeded) {
         if ((rc = new_event_pair(s->ev_main))) return rc;
         KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream));
-        if ((rc = kvq_seeded_launch(s, P, d_data, nbytes, s->d_chunk_off.as<uint32_t>(), nchunks, fpos_base, maxchunk))) return rc;
+        KvqParams PS = P;                          // counters and error of this batch are staged until it is validated
+        PS.ctr = s->d_stage_ctr; PS.err = s->d_err_stage;
+        s->cur_fail = s->d_fail + batch_no;
+        if ((rc = kvq_seeded_launch(s, PS, d_data, nbytes, d_co, nchunks, fpos_base, maxchunk))) return rc;
         KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
         s->main_launches++; s->path_bits |= 1;
         hist_done = true;
@@ -325,7 +382,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
         for (int64_t c0 = 0; c0 < nchunks; c0 += 32768) {
             const uint32_t ny = (uint32_t)std::min<int64_t>(32768, nchunks - c0);
             hipLaunchKernelGGL(kvq_count_lines, dim3(gx, ny), dim3(256), 0, s->stream, d_data,
-                               s->d_chunk_off.as<uint32_t>() + c0, s->d_seg_base.as<uint32_t>() + c0, s->d_seg_cnt.as<uint32_t>());
+                               d_co + c0, s->d_seg_base.as<uint32_t>() + c0, s->d_seg_cnt.as<uint32_t>());
         }
         hipLaunchKernelGGL(kvq_scan_segments, dim3((uint32_t)((nchunks + 3) / 4)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                            s->d_seg_base.as<uint32_t>(), s->d_seg_cnt.as<uint32_t>(), s->d_chunk_nrec.as<uint32_t>());
@@ -345,7 +402,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
             for (int64_t c0 = 0; c0 < nchunks; c0 += 32768) {
                 const uint32_t ny = (uint32_t)std::min<int64_t>(32768, nchunks - c0);
                 hipLaunchKernelGGL(kvq_index_records, dim3(gx, ny), dim3(256), 0, s->stream, d_data,
-                                   s->d_chunk_off.as<uint32_t>() + c0, s->d_seg_base.as<uint32_t>() + c0, s->d_seg_cnt.as<uint32_t>(),
+                                   d_co + c0, s->d_seg_base.as<uint32_t>() + c0, s->d_seg_cnt.as<uint32_t>(),
                                    s->d_chunk_nrec.as<uint32_t>() + c0, s->d_rec_base.as<uint32_t>() + c0,
                                    s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>());
             }
@@ -362,6 +419,9 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
             }
         }
     }
+    if (use_seeded)
+        hipLaunchKernelGGL(kvq_commit_batch, dim3(1), dim3(256), 0, s->stream, s->d_stage_ctr, s->d_ctr, s->d_err_stage, s->d_err,
+                           (const unsigned int *)(s->d_fail + batch_no), s->d_arena_n, (const unsigned int *)(s->d_range + batch_no));
     // hits of this batch = arena[range[batch_no], range[batch_no + 1])
     KVQ_HIP(hipMemcpyAsync(s->d_range + batch_no + 1, s->d_arena_n, 4, hipMemcpyDeviceToDevice, s->stream));
     hipLaunchKernelGGL(kvq_fold_hits, dim3(64), dim3(256), 0, s->stream, P, d_data, fpos_base,
@@ -378,7 +438,7 @@ extern "C" int32_t kvq_scan_device(kvq_scan *s, const void *d_data, int64_t nbyt
     b.chunk_off.assign(chunk_off, chunk_off + nchunks + 1);
     s->batches.push_back(b);
     s->parsed += nbytes; s->total += nbytes;
-    return run_batch(s, (const uint8_t *)d_data, nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1);
+    return run_batch(s, (const uint8_t *)d_data, nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1, false);
 }
 
 extern "C" int32_t kvq_scan_host(kvq_scan *s, const void *h_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base)
@@ -387,28 +447,56 @@ extern "C" int32_t kvq_scan_host(kvq_scan *s, const void *h_data, int64_t nbytes
     if (nbytes <= 0) return KVQ_OK;
     // the staging buffer is reused: the previous batch must have drained
     KVQ_HIP(hipStreamSynchronize(s->stream));
+    s->pool.used = 0;                      // every earlier batch has drained: recycle its tables
     int rc = s->d_stage.ensure((size_t)nbytes + 64); if (rc) return rc;
     KVQ_HIP(hipMemcpyAsync(s->d_stage.p, h_data, (size_t)nbytes, hipMemcpyHostToDevice, s->stream));
     Batch b; b.d_data = nullptr; b.nbytes = nbytes; b.fpos_base = fpos_base;
     s->batches.push_back(b);
     s->host_batches = true;
     s->parsed += nbytes; s->total += nbytes;
-    return run_batch(s, s->d_stage.as<uint8_t>(), nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1);
+    rc = run_batch(s, s->d_stage.as<uint8_t>(), nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1, false);
+    if (rc || !(s->path_bits & 1)) return rc;
+    // the staging buffer is about to be reused: learn now whether the seed-filter pass of this
+    // batch was validated; if not, scan the batch again exactly while the text is still here
+    unsigned int fail = 0;
+    KVQ_HIP(hipStreamSynchronize(s->stream));
+    KVQ_HIP(hipMemcpy(&fail, s->d_fail + (s->batches.size() - 1), 4, hipMemcpyDeviceToHost));
+    if (!fail) return KVQ_OK;
+    s->batches.back().redone = true;
+    Batch again; again.d_data = nullptr; again.nbytes = nbytes; again.fpos_base = fpos_base; again.redone = true; again.is_redo = true;
+    s->batches.push_back(again);
+    s->path_bits |= 4;
+    return run_batch(s, s->d_stage.as<uint8_t>(), nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1, true);
 }
 
 static int finish_once(kvq_scan *s)
 {
     KVQ_HIP(hipStreamSynchronize(s->stream));
+    // batches whose seed-filter pass failed validation (a tile's speculated record split
+    // disagreed with the newline count, or a record outgrew the tile look-ahead) were rolled
+    // back on the device: scan those again with the exhaustive kernels (device batches only;
+    // host batches were redone on the spot)
+    if (!s->batches.empty() && (s->path_bits & 1)) {
+        std::vector<unsigned int> fail(s->batches.size());
+        KVQ_HIP(hipMemcpy(fail.data(), s->d_fail, fail.size() * 4, hipMemcpyDeviceToHost));
+        bool any = false;
+        const size_t nb = s->batches.size();
+        for (size_t b = 0; b < nb; b++) {
+            if (!fail[b] || s->batches[b].redone || !s->batches[b].d_data) continue;
+            s->batches[b].redone = true;
+            Batch again = s->batches[b]; again.is_redo = true;
+            s->batches.push_back(again);
+            s->path_bits |= 4; any = true;
+            int rc = run_batch(s, again.d_data, again.nbytes, again.chunk_off.data(), (int64_t)again.chunk_off.size() - 1,
+                               again.fpos_base, s->batches.size() - 1, true);
+            if (rc) return rc;
+        }
+        if (any) KVQ_HIP(hipStreamSynchronize(s->stream));
+    }
     unsigned char small[32];
     KVQ_HIP(hipMemcpy(small, s->d_small.p, 32, hipMemcpyDeviceToHost));
-    unsigned int n_hits, spec_fail; unsigned long long blob_n, err;
-    memcpy(&n_hits, small, 4); memcpy(&blob_n, small + 8, 8); memcpy(&err, small + 16, 8); memcpy(&spec_fail, small + 24, 4);
-    if (spec_fail && !s->seeded_off) {
-        // a tile's speculated record split disagreed with the newline count (or a record
-        // outgrew the tile look-ahead): nothing of this pass is trusted, scan again exactly
-        s->seeded_off = true; s->path_bits = 4;
-        return KVQ_NEED_RESCAN;
-    }
+    unsigned int n_hits; unsigned long long blob_n, err;
+    memcpy(&n_hits, small, 4); memcpy(&blob_n, small + 8, 8); memcpy(&err, small + 16, 8);
     if (err != ~0ull) {
         // first malformed record in stream order (workhorse.c:1037-1048)
         const long fpos = (long)(err >> 16); const int kind = (int)((err >> 8) & 0xFF); const int ch = (int)(err & 0xFF);
@@ -469,11 +557,14 @@ int kvq_scan_finish_internal(kvq_scan *s)
         if (s->host_batches) return KVQ_NEED_RESCAN;
         // device batches are still resident: replay them into the larger arena
         std::vector<Batch> again; again.swap(s->batches);
-        drop_events(s); s->main_launches = 0;
+        drop_events(s); s->main_launches = 0; s->path_bits = 0;
         if ((rc = reset_device_state(s))) return rc;
+        s->pool.used = 0;
         for (size_t b = 0; b < again.size(); b++) {
-            s->batches.push_back(again[b]);
-            rc = run_batch(s, again[b].d_data, again[b].nbytes, again[b].chunk_off.data(), (int64_t)again[b].chunk_off.size() - 1, again[b].fpos_base, b);
+            if (again[b].is_redo) continue;            // the exhaustive redo of a failed batch: its original is replayed and judged afresh
+            Batch nb = again[b]; nb.redone = false;
+            s->batches.push_back(nb);
+            rc = run_batch(s, nb.d_data, nb.nbytes, nb.chunk_off.data(), (int64_t)nb.chunk_off.size() - 1, nb.fpos_base, s->batches.size() - 1, false);
             if (rc) return rc;
         }
     }
