@@ -84,6 +84,7 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     from kvarq_amd import _lib, scan, synth
+    from kvarq_amd import dist as kdist
     L_ = _lib.lib()
     if L_.kvq_device_count() <= 0:
         raise SystemExit('bench.py needs an MI355X: libkvarq_hip has no CPU path')
@@ -113,15 +114,17 @@ def main():
     if real is not None and k > 1:
         assert list(real[:k]) == list(offs[:k]), 'analytic chunk cuts disagree with the chunker'
 
-    # batches < 2 GiB, cut at chunk boundaries; the base pointer is aligned down to 16 bytes
-    batches, i = [], 0
-    while i < len(offs) - 1:
-        j = i
-        while j + 1 < len(offs) and offs[j + 1] - (offs[i] & ~15) < (1 << 30):
-            j += 1
+    # equal batches of at most 1 GiB, cut at chunk boundaries; the base pointer is aligned down to 16 bytes
+    nb = max(1, -(-(n * rb) // (1 << 30)))
+    nch = len(offs) - 1
+    cuts = [round(k * nch / nb) for k in range(nb + 1)]
+    batches = []
+    for k in range(nb):
+        i, j = cuts[k], cuts[k + 1]
+        if j <= i:
+            continue
         base = int(offs[i]) & ~15
         batches.append((base, int(offs[j]) - base, (offs[i:j + 1] - base).copy()))
-        i = j
 
     table = scan.Table(seqs, **cfg)
     if world > 1:
@@ -139,10 +142,7 @@ def main():
             scanner.scan_device(d_data.ptr + base, nbytes, co, fpos_base=fpos0 + base)
         r = scanner.finish(hits=False)      # hits, hit bytes and counters are on the host (C arrays); no Python tuples here
         if world > 1:
-            longest = ctr[_lib.CTR_LONGEST].clone()
-            dist.all_reduce(ctr, op=dist.ReduceOp.SUM)                  # hit/coverage arrays over xGMI
-            dist.all_reduce(longest, op=dist.ReduceOp.MAX)
-            ctr[_lib.CTR_LONGEST] = longest
+            kdist.reduce_counters(ctr, dist)                            # hit/coverage arrays over xGMI (one sum all-reduce)
         return r
 
     def sync():
@@ -206,6 +206,16 @@ def main():
                      'algorithmic_bytes_per_launch': bytes_per_launch,
                      'all_kernels_ms_per_step': kern_ms / args.steps},
     }
+    # HBM bytes per launch of the dominant kernel from the PMC passes of this same command
+    # (profiles/, collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes)
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')) as f:
+            pmc = json.load(f)
+        if pmc.get('reads_per_gpu') == n and pmc.get('kernel') == out['roofline']['kernel']:
+            out['roofline']['traffic'] = pmc['hbm_bytes_per_launch']
+            out['roofline']['traffic_source'] = 'profiles/round1_pmc_traffic.json'
+    except (IOError, ValueError):
+        pass
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(g, seqs, cfg, L, rb, args.cpu_seconds)
     print(json.dumps(out))
@@ -220,7 +230,8 @@ def cpu_baseline(g, seqs, cfg, L, rb, seconds):
     repo's C restatement of it (oracle/kvarq_oracle.c); both with one worker per core"""
     from kvarq_amd import synth
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a share of 16 host cores: that is the baseline's thread count
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
     probe = synth.reads(g, 0, 4000 * min(cores, 16), L)
     t0 = time.perf_counter()
     O.scan_memory(probe, seqs, nthreads=cores, **cfg)
