@@ -557,80 +557,93 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                 }
             }
             STAMP(4);
-            // seed filter: this lane's slice of the read's 8-mer positions.  Bases come in aligned
-            // dwords; every base rolls the 2-bit code and looks it up in the 2-bit bitmap; the
-            // answers pile up in registers (2 bits per base slot) and are sorted out after the loop
-            int p0 = 0, p1 = 0;
+            // seed filter.  (1) the G lanes of a read pack its bases to 2 bits each, 16 per dword, into
+            // the record's own score line (dead after the trim); (2) every lane takes a slice of the
+            // 8-mer positions, pulls the 16-bit code of each out of the packed words with one
+            // v_alignbit, looks it up in the 2-bit bitmap and piles the answers up in registers
+            int p0 = 0, p1 = 0; uint32_t pkb = 0;
             if (have && rl >= P.minreadlength && !(dbg & 2u)) {                                        // 1100
                 const int NP = rl - (SK - 1);
                 const int per = (NP + (int)G - 1) >> lg;
                 p0 = (int)gl * per; if (p0 > NP) p0 = NP;
                 p1 = p0 + per; if (p1 > NP) p1 = NP;
             }
-            for (int c0 = p0; __any(c0 < p1); c0 += 48) {                  // one round unless a slice exceeds 48 positions
-                const bool act = c0 < p1;
-                const int c1 = act ? (p1 - c0 < 48 ? p1 : c0 + 48) : c0;
-                // base slot u = 4k + b of dword k; slot u finishes the 8-mer at position c0 + u - (skip + 7)
-                const uint32_t w0 = (roff + (uint32_t)c0) & ~3u;
-                const int skip7 = (int)(roff + (uint32_t)c0 - w0) + (SK - 1);
-                const int nd = act ? ((c1 - c0) + skip7 + 3) >> 2 : 0;      // dwords to stream (<= 15)
-                uint64_t acc = 0, acc_lo = 0;
-                uint32_t code = 0;
-                uint32_t x = *reinterpret_cast<const uint32_t *>(&S.buf[w0]);
-                int ndmax = nd;
-#pragma unroll
-                for (int dd = 32; dd >= 1; dd >>= 1) { const int o = __shfl_xor(ndmax, dd, 64); ndmax = o > ndmax ? o : ndmax; }
-                ndmax = (ndmax + 1) & ~1;                                   // dwords are streamed in pairs
-                uint32_t x1 = *reinterpret_cast<const uint32_t *>(&S.buf[w0 + 4u]);
-                for (int kd = 0; kd < ndmax; kd += 2) {
-                    // next pair first, so that its latency hides behind this pair's work
-                    const uint32_t wn = w0 + 4u * (uint32_t)(kd + 2);
-                    const uint32_t wq = wn + 8u <= ST_BUF ? wn : w0;
-                    uint2 xn;
-                    xn.x = *reinterpret_cast<const uint32_t *>(&S.buf[wq]); xn.y = *reinterpret_cast<const uint32_t *>(&S.buf[wq + 4u]);
-                    uint32_t cds[8], wv[8];
-#pragma unroll
-                    for (int bb = 0; bb < 8; bb++) {
-                        const uint32_t c2 = ((bb < 4 ? x : x1) >> (8 * (bb & 3) + 1)) & 3u;
-                        code = (code >> 2) | (c2 << 14);
-                        cds[bb] = code;
-                    }
-#pragma unroll
-                    for (int bb = 0; bb < 8; bb++) wv[bb] = S.bm2[cds[bb] >> 4];
-                    uint32_t nib = 0;
-#pragma unroll
-                    for (int bb = 0; bb < 8; bb++) nib |= ((wv[bb] >> ((cds[bb] & 15u) << 1)) & 3u) << (2 * bb);
-                    if (kd == 8) { acc_lo = acc; acc = 0; }
-                    acc |= (uint64_t)nib << (8 * (kd & 7));
-                    x = xn.x; x1 = xn.y;
+            {
+                // score line of this record starts at nl[m + 2] + 1 (all lanes of the group agree)
+                uint32_t sscore_l = 0; int nw = 0;
+                if (have && rl >= P.minreadlength && !(dbg & 2u)) {
+                    sscore_l = (uint32_t)S.nl[jn + 4u * k + 2u] + 1u;
+                    nw = (rl + 15) >> 4;
                 }
-                if (ndmax <= 8) { acc_lo = acc; acc = 0; }
-                // valid slots: skip7 <= u < skip7 + (c1 - c0); bit 0 of a pair = anchor hit, bit 1 = hit anywhere.
-                // Keep anchor hits of valid slots and "anywhere" hits of the read's fixed head / tail blocks only
-                const int ulo = skip7, uhi = skip7 + (c1 - c0);
-                for (int half = 0; half < 2; half++) {
-                    uint64_t h = half ? acc : acc_lo;
-                    int lo = ulo - 32 * half, hi = uhi - 32 * half;
-                    lo = lo < 0 ? 0 : (lo > 32 ? 32 : lo); hi = hi < 0 ? 0 : (hi > 32 ? 32 : hi);
+                pkb = (sscore_l + 3u) & ~3u;
+                for (int i = (int)gl; __any(i < nw); i += (int)G) {
+                    if (i < nw) {
+                        const uint32_t src = roff + 16u * (uint32_t)i, w = src & ~3u, sh8 = (src & 3u) * 8u;
+                        uint32_t d[5];
+#pragma unroll
+                        for (int t = 0; t < 5; t++) d[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
+                        uint32_t c = 0;
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const uint32_t by = __builtin_amdgcn_alignbit(d[t + 1], d[t], sh8);          // bases 4t..4t+3 of this word
+                            c |= ((((by >> 1) & 0x03030303u) * 0x01041040u) >> 24) << (8 * t);
+                        }
+                        *reinterpret_cast<uint32_t *>(&S.buf[pkb + 4u * (uint32_t)i]) = c;
+                    }
+                }
+            }
+            for (int c0 = p0; __any(c0 < p1); c0 += 32) {                  // one round unless a slice exceeds 32 positions
+                const bool act = c0 < p1;
+                const int c1 = act ? (p1 - c0 < 32 ? p1 : c0 + 32) : c0;
+                uint64_t h64 = 0;
+                if (__any(act)) {
+                    const uint32_t wi = (uint32_t)c0 >> 4, bo = ((uint32_t)c0 & 15u) * 2u;
+                    uint32_t W[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) W[t] = *reinterpret_cast<const uint32_t *>(&S.buf[pkb + 4u * (wi + (uint32_t)t)]);
+                    // the code stream from position c0 on: R0 = positions c0.., R1 = c0+16.., R2 = c0+32..
+                    const uint32_t R0 = __builtin_amdgcn_alignbit(W[1], W[0], bo), R1 = __builtin_amdgcn_alignbit(W[2], W[1], bo),
+                                   R2 = __builtin_amdgcn_alignbit(W[3], W[2], bo);
+                    uint32_t lo32 = 0, hi32 = 0;
+#pragma unroll
+                    for (int j = 0; j < 32; j++) {
+                        const uint32_t win = j < 16 ? __builtin_amdgcn_alignbit(R1, R0, 2 * j) : __builtin_amdgcn_alignbit(R2, R1, 2 * (j - 16));
+                        const uint32_t wv = S.bm2[(win >> 4) & 0xFFFu];
+                        const uint32_t v = (wv >> ((win << 1) & 31u)) & 3u;
+                        if (j < 16) lo32 |= v << (2 * j); else hi32 |= v << (2 * (j - 16));
+                    }
+                    h64 = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
+                }
+                // slot u = position c0 + u; bit 0 of a pair = anchor hit, bit 1 = hit anywhere.  Keep anchor hits
+                // of valid slots and "anywhere" hits of the read's fixed head / tail blocks only
+                {
+                    const int hi = act ? c1 - c0 : 0;
                     uint64_t keep = 0;
-                    if (hi > lo) {
-                        const uint64_t upto_hi = hi >= 32 ? ~0ull : ((1ull << (2 * hi)) - 1ull);
-                        keep = (upto_hi & ~((1ull << (2 * lo)) - 1ull)) & 0x5555555555555555ull;
+                    if (hi > 0) {
+                        keep = (hi >= 32 ? ~0ull : ((1ull << (2 * hi)) - 1ull)) & 0x5555555555555555ull;
                         for (int j = 0; j <= P.maxerrors; j++) {
-                            const int uh = j * SK - c0 + skip7 - 32 * half;                 // head block j
-                            const int ut = rl - (j + 1) * SK - c0 + skip7 - 32 * half;      // tail block j
-                            if (uh >= lo && uh < hi) keep |= 2ull << (2 * uh);
-                            if (ut >= lo && ut < hi) keep |= 2ull << (2 * ut);
+                            const int uh = j * SK - c0;                                 // head block j
+                            const int ut = rl - (j + 1) * SK - c0;                      // tail block j
+                            if (uh >= 0 && uh < hi) keep |= 2ull << (2 * uh);
+                            if (ut >= 0 && ut < hi) keep |= 2ull << (2 * ut);
                         }
                     }
-                    h &= keep;
-                    while (__any(act && h != 0)) {
-                        if (act && h) {
+                    uint64_t h = h64 & keep;
+                    for (;;) {
+                        const uint64_t mm = __ballot(h != 0);
+                        if (!mm) break;
+                        // one LDS atomic per wave and round; the code comes back out of the packed words
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&S.qn, (uint32_t)__popcll(mm));
+                        base = rfl(base);
+                        if (h) {
                             const int bit = __ffsll((long long)h) - 1; h &= h - 1ull;
-                            const int pp = c0 + (bit >> 1) + 32 * half - skip7;
+                            const int pp = c0 + (bit >> 1);
                             const uint32_t kind = (uint32_t)(bit & 1);
-                            const uint32_t cd = lds_code8(S, roff + (uint32_t)pp);
-                            const uint32_t idx = atomicAdd(&S.qn, 1u);
+                            const uint32_t wq = pkb + 4u * ((uint32_t)pp >> 4);
+                            const uint32_t cd = __builtin_amdgcn_alignbit(*reinterpret_cast<const uint32_t *>(&S.buf[wq + 4u]),
+                                                                          *reinterpret_cast<const uint32_t *>(&S.buf[wq]), ((uint32_t)pp & 15u) * 2u) & 0xFFFFu;
+                            const uint32_t idx = base + (uint32_t)__popcll(mm & kvq_lanemask_lt());
                             if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)pp << 16), cd | (kind << 16));
                             else S.fallback = 1u;                                                      // queue full: the tile is rescanned exhaustively
                         }
@@ -681,13 +694,17 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                     verify_item(P, S, active, rec, p, kind, en, tile_fpos);
                 }
             }
-            __syncthreads();
-            if (tid == 0) { S.qn = 0; S.q2n = 0; }
-            __syncthreads();
+            __syncthreads();                                   // everyone is done with the queues and this pass's reads
+            if (pass0 + RP < nrec) {                           // another pass follows: empty the queues for it
+                if (tid == 0) { S.qn = 0; S.q2n = 0; }
+                __syncthreads();
+            }
             STAMP(7);
         }
+        // (the barrier that ended the last pass also protects buf against the next tile's fill;
+        // the queues are emptied again in P1 of the next tile)
         if (tid == 0 && S.fallback) atomicOr(&tile_report[g], TR_FLAG_FALLBACK);
-        __syncthreads();
+        if (nrec == 0) __syncthreads();
     }
 
     if ((dbg & 16u) && tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&P.ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);

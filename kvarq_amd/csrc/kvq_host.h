@@ -91,6 +91,7 @@ struct kvq_scan {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_all, ev_main;
     double ms_all = 0, ms_main = 0; int64_t main_launches = 0;
     // results on the host
+    uint8_t *pin = nullptr; size_t pin_cap = 0;   // pinned landing buffer of finish
     std::vector<int32_t> r_seq_nr, r_seq_pos, r_length, r_readlength;
     std::vector<int64_t> r_file_pos, r_hitseq_off;
     std::vector<uint8_t> r_blob;

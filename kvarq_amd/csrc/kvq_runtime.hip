@@ -8,6 +8,10 @@
 #include <mutex>
 #include <stdarg.h>
 #include <string.h>
+#include <chrono>
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static const bool g_timing = getenv("KVQ_TIMING") != nullptr;
 
 // internal: arena too small or speculation failed; the caller must rescan
 #define KVQ_NEED_RESCAN (-2)
@@ -267,6 +271,7 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     drop_events(s);
     if (s->own_ctr && s->d_ctr) (void)hipFree(s->d_ctr);
+    if (s->pin) (void)hipHostFree(s->pin);
     DevBuf *bufs[] = { &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
                        &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
     for (DevBuf *b : bufs) b->release();
@@ -281,12 +286,15 @@ extern "C" void kvq_scan_force_exhaustive(kvq_scan *s, int32_t on) { s->force_ex
 extern "C" int32_t kvq_scan_reset(kvq_scan *s)
 {
     kvq_clear_error();
+    const double tr0 = now_ms();
     KVQ_HIP(hipStreamSynchronize(s->stream));
     drop_events(s);
     s->batches.clear(); s->host_batches = false; s->records = 0; s->parsed = 0; s->total = 0;
     s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->path_bits = 0;
     s->pool.used = 0;
-    return reset_device_state(s);
+    const int rr = reset_device_state(s);
+    if (g_timing) fprintf(stderr, "reset host %.3f ms\n", now_ms() - tr0);
+    return rr;
 }
 
 static KvqParams make_params(const kvq_scan *s)
@@ -318,6 +326,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
                      int64_t fpos_base, size_t batch_no, bool exhaustive_only)
 {
     const kvq_table *t = s->t;
+    const double tb0 = now_ms();
     if (nbytes <= 0 || nchunks <= 0) return KVQ_OK;
     if (nbytes >= (1ll << 31)) { kvq_set_error(KVQ_ERR_RUNTIME, "batch of %lld bytes is too large (< 2 GiB)", (long long)nbytes); return KVQ_ERR_RUNTIME; }
     if (batch_no >= KVQ_MAX_BATCHES) { kvq_set_error(KVQ_ERR_RUNTIME, "too many batches in one scan"); return KVQ_ERR_RUNTIME; }
@@ -428,6 +437,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
                        (const unsigned int *)(s->d_range + batch_no), (const unsigned int *)(s->d_range + batch_no + 1));
     KVQ_HIP(hipEventRecord(s->ev_all.back().second, s->stream));
     KVQ_HIP(hipGetLastError());
+    if (g_timing) fprintf(stderr, "run_batch host %.3f ms\n", now_ms() - tb0);
     return KVQ_OK;
 }
 
@@ -471,7 +481,9 @@ extern "C" int32_t kvq_scan_host(kvq_scan *s, const void *h_data, int64_t nbytes
 
 static int finish_once(kvq_scan *s)
 {
+    const double t0 = now_ms();
     KVQ_HIP(hipStreamSynchronize(s->stream));
+    const double t1 = now_ms();
     // batches whose seed-filter pass failed validation (a tile's speculated record split
     // disagreed with the newline count, or a record outgrew the tile look-ahead) were rolled
     // back on the device: scan those again with the exhaustive kernels (device batches only;
@@ -515,20 +527,48 @@ static int finish_once(kvq_scan *s)
         return KVQ_NEED_RESCAN;
     }
     // results to the host
-    std::vector<KvqHit> hits(n_hits);
-    if (n_hits) KVQ_HIP(hipMemcpy(hits.data(), s->d_arena.p, (size_t)n_hits * sizeof(KvqHit), hipMemcpyDeviceToHost));
-    std::vector<uint8_t> blob((size_t)blob_n);
-    if (blob_n) KVQ_HIP(hipMemcpy(blob.data(), s->d_blob.p, (size_t)blob_n, hipMemcpyDeviceToHost));
-    KVQ_HIP(hipMemcpy(s->h_ctr.data(), s->d_ctr, (size_t)s->t->ctr_len * 8, hipMemcpyDeviceToHost));
+    // one pinned host buffer takes hits, hit bytes and counters in three async copies
+    const size_t hits_b = ((size_t)n_hits * sizeof(KvqHit) + 255) & ~(size_t)255, blob_b = ((size_t)blob_n + 255) & ~(size_t)255;
+    const size_t ctr_b = (size_t)s->t->ctr_len * 8;
+    if (hits_b + blob_b + ctr_b > s->pin_cap) {
+        if (s->pin) (void)hipHostFree(s->pin);
+        s->pin = nullptr; s->pin_cap = 0;
+        const size_t want = (hits_b + blob_b + ctr_b) * 5 / 4 + (1 << 20);
+        if (hipHostMalloc((void **)&s->pin, want, hipHostMallocDefault) != hipSuccess) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); return KVQ_ERR_MEMORY; }
+        s->pin_cap = want;
+    }
+    const KvqHit *hits = reinterpret_cast<const KvqHit *>(s->pin);
+    const uint8_t *blob = s->pin + hits_b;
+    if (n_hits) KVQ_HIP(hipMemcpyAsync(s->pin, s->d_arena.p, (size_t)n_hits * sizeof(KvqHit), hipMemcpyDeviceToHost, s->stream));
+    if (blob_n) KVQ_HIP(hipMemcpyAsync(s->pin + hits_b, s->d_blob.p, (size_t)blob_n, hipMemcpyDeviceToHost, s->stream));
+    KVQ_HIP(hipMemcpyAsync(s->pin + hits_b + blob_b, s->d_ctr, ctr_b, hipMemcpyDeviceToHost, s->stream));
+    KVQ_HIP(hipStreamSynchronize(s->stream));
+    memcpy(s->h_ctr.data(), s->pin + hits_b + blob_b, ctr_b);
 
+    const double t2 = now_ms();
+    // canonical order (file_pos, seq_nr, class/ordinal): hits spread evenly over file_pos, so a
+    // counting sort into file_pos buckets followed by tiny in-bucket sorts is linear
     std::vector<uint32_t> order(n_hits);
-    for (uint32_t i = 0; i < n_hits; i++) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        const KvqHit &a = hits[x], &b = hits[y];
-        if (a.fpos != b.fpos) return a.fpos < b.fpos;
-        if (a.seq_nr != b.seq_nr) return a.seq_nr < b.seq_nr;
-        return a.key < b.key;
-    });
+    if (n_hits) {
+        int64_t lo = hits[0].fpos, hi = hits[0].fpos;
+        for (uint32_t i = 1; i < n_hits; i++) { lo = std::min(lo, hits[i].fpos); hi = std::max(hi, hits[i].fpos); }
+        uint32_t nb = 1; while (nb < n_hits / 2 && nb < (1u << 22)) nb <<= 1;
+        const double scale = (double)nb / ((double)(hi - lo) + 1.0);
+        std::vector<uint32_t> start((size_t)nb + 1, 0), bucket(n_hits);
+        for (uint32_t i = 0; i < n_hits; i++) { bucket[i] = (uint32_t)((double)(hits[i].fpos - lo) * scale); if (bucket[i] >= nb) bucket[i] = nb - 1; start[bucket[i] + 1]++; }
+        for (uint32_t b = 0; b < nb; b++) start[b + 1] += start[b];
+        std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+        for (uint32_t i = 0; i < n_hits; i++) order[fill[bucket[i]]++] = i;
+        auto less = [&](uint32_t x, uint32_t y) {
+            const KvqHit &a = hits[x], &b = hits[y];
+            if (a.fpos != b.fpos) return a.fpos < b.fpos;
+            if (a.seq_nr != b.seq_nr) return a.seq_nr < b.seq_nr;
+            return a.key < b.key;
+        };
+        for (uint32_t b = 0; b < nb; b++)
+            if (start[b + 1] - start[b] > 1) std::sort(order.begin() + start[b], order.begin() + start[b + 1], less);
+    }
+    const double t3 = now_ms();
     s->r_seq_nr.resize(n_hits); s->r_seq_pos.resize(n_hits); s->r_length.resize(n_hits); s->r_readlength.resize(n_hits);
     s->r_file_pos.resize(n_hits); s->r_hitseq_off.resize((size_t)n_hits + 1); s->r_blob.resize((size_t)blob_n);
     int64_t at = 0;
@@ -536,7 +576,7 @@ static int finish_once(kvq_scan *s)
         const KvqHit &h = hits[order[i]];
         s->r_seq_nr[i] = h.seq_nr; s->r_file_pos[i] = h.fpos; s->r_seq_pos[i] = h.seq_pos; s->r_length[i] = h.length; s->r_readlength[i] = h.readlength;
         s->r_hitseq_off[i] = at;
-        if (h.length > 0) memcpy(&s->r_blob[(size_t)at], &blob[h.blob_off], (size_t)h.length);
+        if (h.length > 0) memcpy(&s->r_blob[(size_t)at], blob + h.blob_off, (size_t)h.length);
         at += h.length;
     }
     s->r_hitseq_off[n_hits] = at;
@@ -545,6 +585,7 @@ static int finish_once(kvq_scan *s)
     for (auto &e : s->ev_all) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_all += ms; }
     for (auto &e : s->ev_main) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_main += ms; }
     s->finished = true;
+    if (g_timing) fprintf(stderr, "finish: wait %.3f  d2h %.3f  sort %.3f  build %.3f ms (%u hits)\n", t1 - t0, t2 - t1, t3 - t2, now_ms() - t3, n_hits);
     return KVQ_OK;
 }
 
