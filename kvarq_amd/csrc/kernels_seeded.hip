@@ -557,145 +557,164 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                 }
             }
             STAMP(4);
-            // seed filter.  (1) the G lanes of a read pack its bases to 2 bits each, 16 per dword, into
-            // the record's own score line (dead after the trim); (2) every lane takes a slice of the
-            // 8-mer positions, pulls the 16-bit code of each out of the packed words with one
-            // v_alignbit, looks it up in the 2-bit bitmap and piles the answers up in registers
-            int p0 = 0, p1 = 0; uint32_t pkb = 0;
-            if (have && rl >= P.minreadlength && !(dbg & 2u)) {                                        // 1100
-                const int NP = rl - (SK - 1);
-                const int per = (NP + (int)G - 1) >> lg;
-                p0 = (int)gl * per; if (p0 > NP) p0 = NP;
-                p1 = p0 + per; if (p1 > NP) p1 = NP;
-            }
-            {
-                // score line of this record starts at nl[m + 2] + 1 (all lanes of the group agree)
-                uint32_t sscore_l = 0; int nw = 0;
-                if (have && rl >= P.minreadlength && !(dbg & 2u)) {
-                    sscore_l = (uint32_t)S.nl[jn + 4u * k + 2u] + 1u;
-                    nw = (rl + 15) >> 4;
+            // filter + verify this pass's reads.  Normally one stretch; when the candidate queues
+            // overflow (dense tables, hit-rich reads) the stretch is redone in halves
+            const uint32_t npass = nrec - pass0 < RP ? nrec - pass0 : RP;
+            uint32_t sub = 0, step = RP;
+            for (;;) {
+                const bool mine = have && rl >= P.minreadlength && !(dbg & 2u) && gr >= sub && gr - sub < step;       // 1100
+                // seed filter.  (1) the G lanes of a read pack its bases to 2 bits each, 16 per dword, into
+                // the record's own score line (dead after the trim); (2) every lane takes a slice of the
+                // 8-mer positions, pulls the 16-bit code of each out of the packed words with one
+                // v_alignbit, looks it up in the 2-bit bitmap and piles the answers up in registers
+                int p0 = 0, p1 = 0; uint32_t pkb = 0;
+                if (mine) {
+                    const int NP = rl - (SK - 1);
+                    const int per = (NP + (int)G - 1) >> lg;
+                    p0 = (int)gl * per; if (p0 > NP) p0 = NP;
+                    p1 = p0 + per; if (p1 > NP) p1 = NP;
                 }
-                pkb = (sscore_l + 3u) & ~3u;
-                for (int i = (int)gl; __any(i < nw); i += (int)G) {
-                    if (i < nw) {
-                        const uint32_t src = roff + 16u * (uint32_t)i, w = src & ~3u, sh8 = (src & 3u) * 8u;
-                        uint32_t d[5];
-#pragma unroll
-                        for (int t = 0; t < 5; t++) d[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
-                        uint32_t c = 0;
-#pragma unroll
-                        for (int t = 0; t < 4; t++) {
-                            const uint32_t by = __builtin_amdgcn_alignbit(d[t + 1], d[t], sh8);          // bases 4t..4t+3 of this word
-                            c |= ((((by >> 1) & 0x03030303u) * 0x01041040u) >> 24) << (8 * t);
-                        }
-                        *reinterpret_cast<uint32_t *>(&S.buf[pkb + 4u * (uint32_t)i]) = c;
-                    }
-                }
-            }
-            for (int c0 = p0; __any(c0 < p1); c0 += 32) {                  // one round unless a slice exceeds 32 positions
-                const bool act = c0 < p1;
-                const int c1 = act ? (p1 - c0 < 32 ? p1 : c0 + 32) : c0;
-                uint64_t h64 = 0;
-                if (__any(act)) {
-                    const uint32_t wi = (uint32_t)c0 >> 4, bo = ((uint32_t)c0 & 15u) * 2u;
-                    uint32_t W[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) W[t] = *reinterpret_cast<const uint32_t *>(&S.buf[pkb + 4u * (wi + (uint32_t)t)]);
-                    // the code stream from position c0 on: R0 = positions c0.., R1 = c0+16.., R2 = c0+32..
-                    const uint32_t R0 = __builtin_amdgcn_alignbit(W[1], W[0], bo), R1 = __builtin_amdgcn_alignbit(W[2], W[1], bo),
-                                   R2 = __builtin_amdgcn_alignbit(W[3], W[2], bo);
-                    uint32_t lo32 = 0, hi32 = 0;
-#pragma unroll
-                    for (int j = 0; j < 32; j++) {
-                        const uint32_t win = j < 16 ? __builtin_amdgcn_alignbit(R1, R0, 2 * j) : __builtin_amdgcn_alignbit(R2, R1, 2 * (j - 16));
-                        const uint32_t wv = S.bm2[(win >> 4) & 0xFFFu];
-                        const uint32_t v = (wv >> ((win << 1) & 31u)) & 3u;
-                        if (j < 16) lo32 |= v << (2 * j); else hi32 |= v << (2 * (j - 16));
-                    }
-                    h64 = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
-                }
-                // slot u = position c0 + u; bit 0 of a pair = anchor hit, bit 1 = hit anywhere.  Keep anchor hits
-                // of valid slots and "anywhere" hits of the read's fixed head / tail blocks only
                 {
-                    const int hi = act ? c1 - c0 : 0;
-                    uint64_t keep = 0;
-                    if (hi > 0) {
-                        keep = (hi >= 32 ? ~0ull : ((1ull << (2 * hi)) - 1ull)) & 0x5555555555555555ull;
-                        for (int j = 0; j <= P.maxerrors; j++) {
-                            const int uh = j * SK - c0;                                 // head block j
-                            const int ut = rl - (j + 1) * SK - c0;                      // tail block j
-                            if (uh >= 0 && uh < hi) keep |= 2ull << (2 * uh);
-                            if (ut >= 0 && ut < hi) keep |= 2ull << (2 * ut);
-                        }
+                    // score line of this record starts at nl[m + 2] + 1 (all lanes of the group agree)
+                    uint32_t sscore_l = 0; int nw = 0;
+                    if (mine) {
+                        sscore_l = (uint32_t)S.nl[jn + 4u * k + 2u] + 1u;
+                        nw = (rl + 15) >> 4;
                     }
-                    uint64_t h = h64 & keep;
-                    for (;;) {
-                        const uint64_t mm = __ballot(h != 0);
-                        if (!mm) break;
-                        // one LDS atomic per wave and round; the code comes back out of the packed words
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&S.qn, (uint32_t)__popcll(mm));
-                        base = rfl(base);
-                        if (h) {
-                            const int bit = __ffsll((long long)h) - 1; h &= h - 1ull;
-                            const int pp = c0 + (bit >> 1);
-                            const uint32_t kind = (uint32_t)(bit & 1);
-                            const uint32_t wq = pkb + 4u * ((uint32_t)pp >> 4);
-                            const uint32_t cd = __builtin_amdgcn_alignbit(*reinterpret_cast<const uint32_t *>(&S.buf[wq + 4u]),
-                                                                          *reinterpret_cast<const uint32_t *>(&S.buf[wq]), ((uint32_t)pp & 15u) * 2u) & 0xFFFFu;
-                            const uint32_t idx = base + (uint32_t)__popcll(mm & kvq_lanemask_lt());
-                            if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)pp << 16), cd | (kind << 16));
-                            else S.fallback = 1u;                                                      // queue full: the tile is rescanned exhaustively
+                    pkb = (sscore_l + 3u) & ~3u;
+                    for (int i = (int)gl; __any(i < nw); i += (int)G) {
+                        if (i < nw) {
+                            const uint32_t src = roff + 16u * (uint32_t)i, w = src & ~3u, sh8 = (src & 3u) * 8u;
+                            uint32_t d[5];
+    #pragma unroll
+                            for (int t = 0; t < 5; t++) d[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
+                            uint32_t c = 0;
+    #pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                const uint32_t by = __builtin_amdgcn_alignbit(d[t + 1], d[t], sh8);          // bases 4t..4t+3 of this word
+                                c |= ((((by >> 1) & 0x03030303u) * 0x01041040u) >> 24) << (8 * t);
+                            }
+                            *reinterpret_cast<uint32_t *>(&S.buf[pkb + 4u * (uint32_t)i]) = c;
                         }
                     }
                 }
-            }
-            STAMP(5);
-            __syncthreads();
-            STAMP(6);
-
-            // ---- P4a: one candidate per lane: index range -> (candidate, entry) work items ----
-            const uint32_t qall = rfl(S.qn);
-            const uint32_t qn = qall < ST_QCAP ? qall : ST_QCAP;
-            if (!(dbg & 1u))
-            for (uint32_t q0 = wave * 64u; q0 < qn; q0 += ST_THREADS) {
-                const uint32_t qi = q0 + lane;
-                uint32_t e0 = 0, ne = 0;
-                if (qi < qn) {
-                    const uint2 cd = S.q1[qi];
-                    const uint32_t *st = (cd.y >> 16) ? X.start_all : X.start_anc;
-                    e0 = st[cd.y & 0xFFFFu]; ne = st[(cd.y & 0xFFFFu) + 1u] - e0;
+                for (int c0 = p0; __any(c0 < p1); c0 += 32) {                  // one round unless a slice exceeds 32 positions
+                    const bool act = c0 < p1;
+                    const int c1 = act ? (p1 - c0 < 32 ? p1 : c0 + 32) : c0;
+                    uint64_t h64 = 0;
+                    if (__any(act)) {
+                        const uint32_t wi = (uint32_t)c0 >> 4, bo = ((uint32_t)c0 & 15u) * 2u;
+                        uint32_t W[4];
+    #pragma unroll
+                        for (int t = 0; t < 4; t++) W[t] = *reinterpret_cast<const uint32_t *>(&S.buf[pkb + 4u * (wi + (uint32_t)t)]);
+                        // the code stream from position c0 on: R0 = positions c0.., R1 = c0+16.., R2 = c0+32..
+                        const uint32_t R0 = __builtin_amdgcn_alignbit(W[1], W[0], bo), R1 = __builtin_amdgcn_alignbit(W[2], W[1], bo),
+                                       R2 = __builtin_amdgcn_alignbit(W[3], W[2], bo);
+                        uint32_t lo32 = 0, hi32 = 0;
+    #pragma unroll
+                        for (int j = 0; j < 32; j++) {
+                            const uint32_t win = j < 16 ? __builtin_amdgcn_alignbit(R1, R0, 2 * j) : __builtin_amdgcn_alignbit(R2, R1, 2 * (j - 16));
+                            const uint32_t wv = S.bm2[(win >> 4) & 0xFFFu];
+                            const uint32_t v = (wv >> ((win << 1) & 31u)) & 3u;
+                            if (j < 16) lo32 |= v << (2 * j); else hi32 |= v << (2 * (j - 16));
+                        }
+                        h64 = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
+                    }
+                    // slot u = position c0 + u; bit 0 of a pair = anchor hit, bit 1 = hit anywhere.  Keep anchor hits
+                    // of valid slots and "anywhere" hits of the read's fixed head / tail blocks only
+                    {
+                        const int hi = act ? c1 - c0 : 0;
+                        uint64_t keep = 0;
+                        if (hi > 0) {
+                            keep = (hi >= 32 ? ~0ull : ((1ull << (2 * hi)) - 1ull)) & 0x5555555555555555ull;
+                            for (int j = 0; j <= P.maxerrors; j++) {
+                                const int uh = j * SK - c0;                                 // head block j
+                                const int ut = rl - (j + 1) * SK - c0;                      // tail block j
+                                if (uh >= 0 && uh < hi) keep |= 2ull << (2 * uh);
+                                if (ut >= 0 && ut < hi) keep |= 2ull << (2 * ut);
+                            }
+                        }
+                        uint64_t h = h64 & keep;
+                        for (;;) {
+                            const uint64_t mm = __ballot(h != 0);
+                            if (!mm) break;
+                            // one LDS atomic per wave and round; the code comes back out of the packed words
+                            uint32_t base = 0;
+                            if (lane == 0) base = atomicAdd(&S.qn, (uint32_t)__popcll(mm));
+                            base = rfl(base);
+                            if (h) {
+                                const int bit = __ffsll((long long)h) - 1; h &= h - 1ull;
+                                const int pp = c0 + (bit >> 1);
+                                const uint32_t kind = (uint32_t)(bit & 1);
+                                const uint32_t wq = pkb + 4u * ((uint32_t)pp >> 4);
+                                const uint32_t cd = __builtin_amdgcn_alignbit(*reinterpret_cast<const uint32_t *>(&S.buf[wq + 4u]),
+                                                                              *reinterpret_cast<const uint32_t *>(&S.buf[wq]), ((uint32_t)pp & 15u) * 2u) & 0xFFFFu;
+                                const uint32_t idx = base + (uint32_t)__popcll(mm & kvq_lanemask_lt());
+                                if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)pp << 16), cd | (kind << 16));   // beyond the cap: dropped, the stretch is redone in halves
+                            }
+                        }
+                    }
                 }
-                const uint32_t inc = kvq_wave_incl_scan(ne);
-                uint32_t base = 0;
-                if (lane == 63 && inc) base = atomicAdd(&S.q2n, inc);
-                base = __shfl(base, 63, 64) + inc - ne;
-                for (uint32_t j = 0; j < ne; j++)
-                    if (base + j < ST_Q2CAP) S.q2[base + j] = (qi << 22) | (e0 + j);
-            }
-            __syncthreads();
+                STAMP(5);
+                __syncthreads();
+                STAMP(6);
 
-            // ---- P4b: one work item per lane ----
-            {
-                const uint32_t q2all = rfl(S.q2n);
-                const uint32_t q2n = q2all < ST_Q2CAP ? q2all : ST_Q2CAP;
-                if (q2all > ST_Q2CAP && tid == 0) S.fallback = 1u;
+                // ---- P4a: one candidate per lane: index range -> (candidate, entry) work items ----
+                const uint32_t qall = rfl(S.qn);
+                const bool over1 = qall > ST_QCAP;                        // candidates were dropped
+                const uint32_t qn = over1 ? 0u : qall;
                 if (!(dbg & 1u))
-                for (uint32_t i0 = wave * 64u; i0 < q2n; i0 += ST_THREADS) {
-                    const uint32_t ii = i0 + lane;
-                    const bool active = ii < q2n;
-                    uint32_t rec = 0, kind = 0; int p = 0; uint64_t en = 0;
-                    if (active) {
-                        const uint32_t it = S.q2[ii];
-                        const uint2 cd = S.q1[it >> 22];
-                        rec = cd.x & 0xFFFFu; p = (int)(cd.x >> 16); kind = cd.y >> 16;
-                        en = (kind ? X.ent_all : X.ent_anc)[it & 0x3FFFFFu];
+                for (uint32_t q0 = wave * 64u; q0 < qn; q0 += ST_THREADS) {
+                    const uint32_t qi = q0 + lane;
+                    uint32_t e0 = 0, ne = 0;
+                    if (qi < qn) {
+                        const uint2 cd = S.q1[qi];
+                        const uint32_t *st = (cd.y >> 16) ? X.start_all : X.start_anc;
+                        e0 = st[cd.y & 0xFFFFu]; ne = st[(cd.y & 0xFFFFu) + 1u] - e0;
                     }
-                    verify_item(P, S, active, rec, p, kind, en, tile_fpos);
+                    const uint32_t inc = kvq_wave_incl_scan(ne);
+                    uint32_t base = 0;
+                    if (lane == 63 && inc) base = atomicAdd(&S.q2n, inc);
+                    base = __shfl(base, 63, 64) + inc - ne;
+                    for (uint32_t j = 0; j < ne; j++)
+                        if (base + j < ST_Q2CAP) S.q2[base + j] = (qi << 22) | (e0 + j);
                 }
+                __syncthreads();
+                const uint32_t q2all = rfl(S.q2n);
+                const bool over = over1 || q2all > ST_Q2CAP;
+                if (over && step > 1u) {
+                    __syncthreads();                                      // everyone has seen the counts
+                    if (tid == 0) { S.qn = 0; S.q2n = 0; }
+                    step >>= 1;
+                    __syncthreads();
+                    continue;
+                }
+                if (over && tid == 0) S.fallback = 1u;                    // one read floods the queues: the batch goes to the exhaustive kernels
+
+                // ---- P4b: one work item per lane ----
+                {
+                    const uint32_t q2n = over ? 0u : q2all;
+                    if (!(dbg & 1u))
+                    for (uint32_t i0 = wave * 64u; i0 < q2n; i0 += ST_THREADS) {
+                        const uint32_t ii = i0 + lane;
+                        const bool active = ii < q2n;
+                        uint32_t rec = 0, kind = 0; int p = 0; uint64_t en = 0;
+                        if (active) {
+                            const uint32_t it = S.q2[ii];
+                            const uint2 cd = S.q1[it >> 22];
+                            rec = cd.x & 0xFFFFu; p = (int)(cd.x >> 16); kind = cd.y >> 16;
+                            en = (kind ? X.ent_all : X.ent_anc)[it & 0x3FFFFFu];
+                        }
+                        verify_item(P, S, active, rec, p, kind, en, tile_fpos);
+                    }
+                }
+                __syncthreads();                                   // everyone is done with the queues and these reads
+                sub += step;
+                if (sub >= npass) break;
+                if (tid == 0) { S.qn = 0; S.q2n = 0; }
+                __syncthreads();
             }
-            __syncthreads();                                   // everyone is done with the queues and this pass's reads
-            if (pass0 + RP < nrec) {                           // another pass follows: empty the queues for it
+            if (pass0 + RP < nrec) {                               // another pass follows: empty the queues for it
                 if (tid == 0) { S.qn = 0; S.q2n = 0; }
                 __syncthreads();
             }

@@ -10,6 +10,8 @@
 #include <mutex>
 #include <string.h>
 #include <zlib.h>
+#include <thread>
+#include <unistd.h>
 
 int64_t kvq_tail_record(const uint8_t *buf, int64_t n);
 int kvq_scan_finish_internal(kvq_scan *s);
@@ -93,6 +95,7 @@ public:
         fd_ = fopen(name.c_str(), "rb");
         if (!fd_) { kvq_set_error(KVQ_ERR_IO, "cannot open file"); return KVQ_ERR_IO; }
         consumed_ = 0; file_done_ = false;
+        fseek(fd_, 0, SEEK_END); file_size_ = ftell(fd_); fseek(fd_, 0, SEEK_SET);
         gz_ = name.size() >= 3 && name.compare(name.size() - 3, 3, ".gz") == 0;     // by suffix (582)
         if (gz_) {
             memset(&zs_, 0, sizeof(zs_));
@@ -116,8 +119,31 @@ public:
         if (file_done_) { *eof = true; return 0; }
         int64_t n = 0;
         if (!gz_) {
-            n = (int64_t)fread(dst, 1, (size_t)cap, fd_);
-            if (ferror(fd_)) { kvq_set_error(KVQ_ERR_IO, "error while reading from file in fastq_read"); return -1; }
+            // plain file: `nthreads` readers pread() disjoint slices straight into the pinned buffer
+            // (the reference's workers share one fread under a mutex, workhorse.c:746,890)
+            const int fdn = fileno(fd_);
+            const int64_t left = file_size_ - consumed_;
+            n = left < cap ? (left < 0 ? 0 : left) : cap;
+            kvq_config cfg; kvq_config_get(&cfg);
+            int nt = cfg.nthreads < 1 ? 1 : (cfg.nthreads > 32 ? 32 : cfg.nthreads);
+            if (n < (4 << 20)) nt = 1;
+            std::atomic<int> bad{0};
+            auto slice = [&](int t) {
+                int64_t a = n * t / nt, b = n * (t + 1) / nt;
+                while (a < b) {
+                    const ssize_t got = pread(fdn, dst + a, (size_t)(b - a), (off_t)(consumed_ + a));
+                    if (got <= 0) { bad = 1; return; }
+                    a += got;
+                }
+            };
+            if (nt == 1) slice(0);
+            else {
+                std::vector<std::thread> th;
+                for (int t = 1; t < nt; t++) th.emplace_back(slice, t);
+                slice(0);
+                for (auto &x : th) x.join();
+            }
+            if (bad.load()) { kvq_set_error(KVQ_ERR_IO, "error while reading from file in fastq_read"); return -1; }
             if (n < cap) { *eof = true; file_done_ = true; }
             consumed_ += n;
         } else {
@@ -201,7 +227,7 @@ private:
     std::vector<std::string> files_; size_t next_ = 0;
     FILE *fd_ = nullptr; bool gz_ = false, file_done_ = true;
     z_stream zs_; bool zs_live_ = false; uint8_t *inbuf_ = nullptr; int64_t remaining_ = 0;
-    int64_t size_ = 0, ftell0_ = 0, consumed_ = 0, fpos_ = 0, total_ = 0;
+    int64_t size_ = 0, ftell0_ = 0, consumed_ = 0, fpos_ = 0, total_ = 0, file_size_ = 0;
 };
 
 // ---------------------------------------------------------------------------

@@ -235,3 +235,26 @@ def test_speculation_failure_falls_back_to_the_exact_split():
     assert r['coverage'].tolist() == o['coverage']
     assert len(o['hits']) > 100
     s.close(); t.close()
+
+
+def test_dense_table_overflows_the_candidate_queues_gracefully():
+    """8x the MTBC table (2112 sequences): the 8-mer bitmap is dense, the candidate queues of a
+    tile overflow and its reads are filtered in smaller stretches -- same hits as the exhaustive
+    kernels, without a rescan"""
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g, 'MTBC', scale=8))
+    data = synth.reads(g, 777, 20000, 150)
+    t = scan.Table(seqs, **cases.PRODUCT)
+    res = []
+    for force in (False, True):
+        s = scan.Scanner(t)
+        s.force_exhaustive(force)
+        s.scan_host(data)
+        res.append(s.finish())
+        s.close()
+    a, b = res
+    assert a['path'] == dict(seeded=True, exhaustive=False, rescanned=False)
+    assert a['hits'] == b['hits'] and a['hitseqs'] == b['hitseqs']
+    assert (a['counters'] == b['counters']).all()
+    assert len(a['hits']) > 300
+    t.close()

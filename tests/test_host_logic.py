@@ -172,3 +172,17 @@ def test_synthetic_generator_matches_numpy_statement():
     t2 = synth.table(g, 'MTBC+barcodes')
     assert len(t2) == 194 and sum(map(len, t2)) == 9480
     assert synth.revcomp(b'AACGTN') == b'NACGTT'                            # kvarq/genes.py:204,257-262
+
+
+def test_reader_with_parallel_pread(tmp_path):
+    """nthreads readers pread() slices of a plain file: same chunks, same bytes accounting"""
+    big = cases.multichunk() * 4                     # > 4 MiB: the parallel path
+    p = str(tmp_path / 'big.fastq')
+    open(p, 'wb').write(big)
+    saved = engine.get_config()
+    try:
+        engine.config(nthreads=5)
+        got, (parsed, total) = plan([p], 3 << 20)
+    finally:
+        engine.config(**saved)
+    assert got == expected_plan([big]) and parsed == total == len(big)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""End-to-end rate of engine.findseqs on files (host read + PCIe + kernels), the
+PCIe-inclusive number DESIGN.md quotes next to the HBM-resident bench value."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gzip  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+from kvarq_amd import _lib, engine, scan, synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000
+L = 150
+rb = synth.record_bytes(L)
+g = synth.genome()
+seqs = synth.both_strands(synth.table(g))
+dg = scan.DeviceBuffer(g.nbytes); dg.upload(g)
+dd = scan.DeviceBuffer(n * rb)
+_lib.lib().kvq_synth_reads_device(dd.ptr, 0, n, L, synth.SEED, dg.ptr, g.nbytes)
+data = dd.download()
+path = '/tmp/kvq_rate.fastq'
+data.tofile(path)
+gzpath = '/tmp/kvq_rate_small.fastq.gz'
+with open(gzpath, 'wb') as f:
+    f.write(gzip.compress(data[:200_000 * rb].tobytes(), 1))
+for nt in (1, 4, 16):
+    engine.config(maxerrors=2, minoverlap=25, minreadlength=25, Amin='.', nthreads=nt)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        r = engine.findseqs(path, seqs)
+        dt = time.perf_counter() - t0
+    print('plain  nthreads=%2d  %.3f s  %.1f M reads/s  %.2f GB/s  hits=%d' % (nt, dt, n / dt / 1e6, n * rb / dt / 1e9, len(r['hits'])))
+t0 = time.perf_counter()
+r = engine.findseqs(gzpath, seqs)
+dt = time.perf_counter() - t0
+print('gzip   200k reads     %.3f s  %.2f M reads/s (single-threaded inflate)  hits=%d' % (dt, 0.2 / dt, len(r['hits'])))
+os.remove(path); os.remove(gzpath)
