@@ -80,8 +80,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # backend nccl = RCCL over xGMI; KVQ_BENCH_BACKEND=gloo only exists to rehearse the
+        # multi-rank flow on a one-GPU box (ranks then share the device)
+        backend = os.environ.get('KVQ_BENCH_BACKEND', 'nccl')
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
 
     from kvarq_amd import _lib, scan, synth
     from kvarq_amd import dist as kdist
@@ -143,6 +150,7 @@ def main():
         r = scanner.finish(hits=False)      # hits, hit bytes and counters are on the host (C arrays); no Python tuples here
         if world > 1:
             kdist.reduce_counters(ctr, dist)                            # hit/coverage arrays over xGMI (one sum all-reduce)
+            torch.cuda.current_stream().synchronize()                   # the next step zeroes ctr on the scan's own stream
         return r
 
     def sync():
