@@ -297,31 +297,38 @@ __device__ __forceinline__ int base_class(uint8_t c)
     return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : 5;
 }
 
-// hits [*range_begin, min(*range_end, cap)) of the arena, one thread per hit.
+// hits [*range_begin, min(*range_end, cap)) of the arena, one wave per hit: the lanes share
+// out the hit's bases (coverage / mutation counters, hit bytes), lane 0 does the per-hit part.
 extern "C" __global__ void __launch_bounds__(256)
 kvq_fold_hits(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base,
               const unsigned int *__restrict__ range_begin, const unsigned int *__restrict__ range_end)
 {
     const uint32_t h0 = *range_begin;
     uint32_t h1 = *range_end; if (h1 > P.arena_cap) h1 = P.arena_cap;
-    for (uint32_t h = h0 + blockIdx.x * blockDim.x + threadIdx.x; h < h1; h += gridDim.x * blockDim.x) {
-        KvqHit hit = P.arena[h];
+    const int lane = kvq_lane();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t h = h0 + wave; h < h1; h += nwaves) {
+        const KvqHit hit = P.arena[h];
         const int s = hit.seq_nr, len = hit.length;
-        atomicAdd(&P.ctr[P.off_nseqhits + s], 1ull);                                  // 435
-        atomicAdd(&P.ctr[P.off_nseqbasehits + s], (unsigned long long)len);           // 434
-        atomicAdd(&P.ctr[KVQ_CTR_HITS_], 1ull);
         const int start = hit.seq_pos > 0 ? hit.seq_pos : 0;                          // analyse.py:70
         const uint8_t *src = data + (hit.fpos - fpos_base) + (hit.seq_pos < 0 ? -hit.seq_pos : 0);
         const uint8_t *seq = P.tab + P.tab_off[s] + start;
         const int64_t at = (int64_t)P.tab_off[s] + start;
-        const unsigned long long boff = atomicAdd(P.blob_n, (unsigned long long)len);
+        unsigned long long boff = 0;
+        if (lane == 0) {
+            atomicAdd(&P.ctr[P.off_nseqhits + s], 1ull);                              // 435
+            atomicAdd(&P.ctr[P.off_nseqbasehits + s], (unsigned long long)len);       // 434
+            atomicAdd(&P.ctr[KVQ_CTR_HITS_], 1ull);
+            boff = atomicAdd(P.blob_n, (unsigned long long)len);
+        }
+        boff = ((unsigned long long)__shfl((unsigned int)(boff >> 32), 0, 64) << 32) | __shfl((unsigned int)boff, 0, 64);
         const bool fits = boff + (unsigned long long)len <= P.blob_cap;
-        for (int j = 0; j < len; j++) {
+        for (int j = lane; j < len; j += 64) {
             const uint8_t c = src[j];
             atomicAdd(&P.ctr[P.off_cov + at + j], 1ull);                              // analyse.py:76
             if (c != seq[j]) atomicAdd(&P.ctr[P.off_mut + (at + j) * 6 + base_class(c)], 1ull);   // analyse.py:77-78
             if (fits) P.blob[boff + j] = c;                                           // 437
         }
-        P.arena[h].blob_off = fits ? (uint32_t)boff : 0xFFFFFFFFu;
+        if (lane == 0) P.arena[h].blob_off = fits ? (uint32_t)boff : 0xFFFFFFFFu;
     }
 }

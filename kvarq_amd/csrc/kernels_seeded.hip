@@ -56,7 +56,15 @@ struct SeedTables {
     const uint64_t *ent_anc, *ent_all;
 };
 
+// the planes kernel (kernels_planes.hip)
+extern "C" __global__ void kvq_scan_planes(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int64_t fpos_base,
+                                           const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ tile_chunk,
+                                           const uint32_t *__restrict__ tile_first, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg);
+size_t kvq_planes_lds_bytes();
+uint32_t kvq_planes_tile_bytes();
+
 struct SeedIndex {
+    int variant = 0;          // 0 = kvq_scan_seeded, 1 = kvq_scan_planes (KVQ_KERNEL=planes)
     DevBuf d_bm2, d_start_anc, d_start_all, d_ent_anc, d_ent_all;
     SeedTables dev;
 };
@@ -78,13 +86,15 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     const int e = cfg.maxerrors;
     if (e < 0 || e > 6) return nullptr;
     const int need = (e + 1) * SK;
+    const char *kv = getenv("KVQ_KERNEL");
+    const int variant = (kv && !strcmp(kv, "planes")) ? 1 : 0;      // which kernel walks the text; the index is the same
     // every accepted alignment must be at least `need` long: class A/B overlaps
     // are >= minoverlap, class C lengths are min(readlength, sequence length)
     if (cfg.minoverlap < need || cfg.minreadlength < need) return nullptr;
     if (cfg.Amin <= 13) return nullptr;          // the kernel relies on '\n' and '\r' closing every quality run (1058)
     for (int s = 0; s < t->nseq; s++) {
         const int len = t->h_off[s + 1] - t->h_off[s];
-        bool ok = len >= need && len <= 4095 && t->h_off[s] < (1 << 20) && s < (1 << 20);
+        bool ok = len >= need + 1 && len <= 4095 && t->h_off[s] < (1 << 20) && s < (1 << 20);   // the shifted anchor set needs one more base
         for (int i = 0; ok && i < len; i++) {
             const uint8_t c = t->h_tab[t->h_off[s] + i];
             ok = (c == 'A' || c == 'C' || c == 'G' || c == 'T');
@@ -99,10 +109,12 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
         const uint8_t *q = &t->h_tab[t->h_off[s]];
         const int len = t->h_off[s + 1] - t->h_off[s];
         const uint64_t hi = ((uint64_t)(uint32_t)t->h_off[s] << 32) | ((uint64_t)(uint32_t)len << 52) | ((uint64_t)(uint32_t)s << 12);
-        for (int j = 0; j <= e; j++) anc.emplace_back(host_code8(q + j * SK), hi | (uint64_t)(j * SK));
+        for (int j = 0; j <= e; j++)
+            for (int sft = 0; sft <= 1; sft++) anc.emplace_back(host_code8(q + j * SK + sft), hi | (uint64_t)(j * SK + sft));
         for (int p = 0; p + SK <= len; p++) all.emplace_back(host_code8(q + p), hi | (uint64_t)p);
     }
     SeedIndex *ix = new SeedIndex();
+    ix->variant = variant;
     std::vector<uint32_t> bm2(4096, 0);
     auto upload = [&](std::vector<std::pair<uint32_t, uint64_t>> &v, int bit, DevBuf &st, DevBuf &en) -> bool {
         std::sort(v.begin(), v.end());
@@ -215,6 +227,7 @@ __device__ __forceinline__ void longest_run64(uint64_t m, int n, int &len, int &
     T = E & (m << L);  if (T) { E = T; L += 1; }
     len = L;
     start = L ? (__ffsll((long long)E) - 1) - L + 1 : 0;
+    if (m == ~0ull) { len = 64; start = 0; }                 // the descent tops out at 63
 }
 
 // longest-run summary of a stretch of score bytes; merge is associative (left, right)
@@ -300,8 +313,14 @@ __device__ __forceinline__ void verify_item(const KvqParams &P, const SeededLds 
                     if (ph + SK <= rl && (kind == 0u || ph < p)) earlier = seed_live(S, roff, rl, ph, seq, seql, ph + d);
                     if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live(S, roff, rl, pt, seq, seql, pt + d);
                 }
-                if (kind == 0u)
-                    for (int jj = 0; jj * SK < q && !earlier; jj++) earlier = seed_live(S, roff, rl, jj * SK - d, seq, seql, jj * SK);
+                if (kind == 0u) {
+                    // anchors sit at sequence offsets 8j and 8j+1 and are looked up at even read positions only
+                    for (int jj = 0; jj <= me && !earlier; jj++)
+                        for (int sft = 0; sft < 2 && !earlier; sft++) {
+                            const int o = jj * SK + sft;
+                            if (o < q && ((o - d) & 1) == 0) earlier = seed_live(S, roff, rl, o - d, seq, seql, o);
+                        }
+                }
                 if (!earlier) { hitAB = canAB; hitC = canC; }
             }
         }
@@ -567,12 +586,14 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                 // the record's own score line (dead after the trim); (2) every lane takes a slice of the
                 // 8-mer positions, pulls the 16-bit code of each out of the packed words with one
                 // v_alignbit, looks it up in the 2-bit bitmap and piles the answers up in registers
-                int p0 = 0, p1 = 0; uint32_t pkb = 0;
+                // only even read positions are looked up (the anchor blocks of a sequence are indexed at
+                // offsets 8j and 8j+1, so an alignment at an odd offset is met through the shifted set)
+                int e0 = 0, e1 = 0; uint32_t pkb = 0;
                 if (mine) {
-                    const int NP = rl - (SK - 1);
-                    const int per = (NP + (int)G - 1) >> lg;
-                    p0 = (int)gl * per; if (p0 > NP) p0 = NP;
-                    p1 = p0 + per; if (p1 > NP) p1 = NP;
+                    const int NPe = (rl - (SK - 1) + 1) >> 1;
+                    const int per = (NPe + (int)G - 1) >> lg;
+                    e0 = (int)gl * per; if (e0 > NPe) e0 = NPe;
+                    e1 = e0 + per; if (e1 > NPe) e1 = NPe;
                 }
                 {
                     // score line of this record starts at nl[m + 2] + 1 (all lanes of the group agree)
@@ -598,60 +619,82 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                         }
                     }
                 }
-                for (int c0 = p0; __any(c0 < p1); c0 += 32) {                  // one round unless a slice exceeds 32 positions
-                    const bool act = c0 < p1;
-                    const int c1 = act ? (p1 - c0 < 32 ? p1 : c0 + 32) : c0;
-                    uint64_t h64 = 0;
+                for (int ee = e0; __any(ee < e1); ee += 16) {                  // one round unless a slice exceeds 16 even positions
+                    const bool act = ee < e1;
+                    uint32_t hbits = 0;                                          // bit j: position 2(ee + j) carries an anchor code
                     if (__any(act)) {
-                        const uint32_t wi = (uint32_t)c0 >> 4, bo = ((uint32_t)c0 & 15u) * 2u;
+                        const uint32_t bit = 4u * (uint32_t)ee;                  // packed stream: 2 bits per base
+                        const uint32_t wi = bit >> 5, bo = bit & 31u;
                         uint32_t W[4];
-    #pragma unroll
+#pragma unroll
                         for (int t = 0; t < 4; t++) W[t] = *reinterpret_cast<const uint32_t *>(&S.buf[pkb + 4u * (wi + (uint32_t)t)]);
-                        // the code stream from position c0 on: R0 = positions c0.., R1 = c0+16.., R2 = c0+32..
                         const uint32_t R0 = __builtin_amdgcn_alignbit(W[1], W[0], bo), R1 = __builtin_amdgcn_alignbit(W[2], W[1], bo),
                                        R2 = __builtin_amdgcn_alignbit(W[3], W[2], bo);
-                        uint32_t lo32 = 0, hi32 = 0;
-    #pragma unroll
-                        for (int j = 0; j < 32; j++) {
-                            const uint32_t win = j < 16 ? __builtin_amdgcn_alignbit(R1, R0, 2 * j) : __builtin_amdgcn_alignbit(R2, R1, 2 * (j - 16));
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const uint32_t win = j < 8 ? __builtin_amdgcn_alignbit(R1, R0, 4 * j) : __builtin_amdgcn_alignbit(R2, R1, 4 * (j - 8));
                             const uint32_t wv = S.bm2[(win >> 4) & 0xFFFu];
-                            const uint32_t v = (wv >> ((win << 1) & 31u)) & 3u;
-                            if (j < 16) lo32 |= v << (2 * j); else hi32 |= v << (2 * (j - 16));
+                            hbits |= ((wv >> ((win << 1) & 31u)) & 1u) << j;
                         }
-                        h64 = (uint64_t)lo32 | ((uint64_t)hi32 << 32);
+                        const int nv = act ? (e1 - ee < 16 ? e1 - ee : 16) : 0;
+                        hbits &= nv >= 16 ? 0xFFFFu : ((1u << nv) - 1u);
                     }
-                    // slot u = position c0 + u; bit 0 of a pair = anchor hit, bit 1 = hit anywhere.  Keep anchor hits
-                    // of valid slots and "anywhere" hits of the read's fixed head / tail blocks only
-                    {
-                        const int hi = act ? c1 - c0 : 0;
-                        uint64_t keep = 0;
-                        if (hi > 0) {
-                            keep = (hi >= 32 ? ~0ull : ((1ull << (2 * hi)) - 1ull)) & 0x5555555555555555ull;
-                            for (int j = 0; j <= P.maxerrors; j++) {
-                                const int uh = j * SK - c0;                                 // head block j
-                                const int ut = rl - (j + 1) * SK - c0;                      // tail block j
-                                if (uh >= 0 && uh < hi) keep |= 2ull << (2 * uh);
-                                if (ut >= 0 && ut < hi) keep |= 2ull << (2 * ut);
+                    for (;;) {
+                        const uint64_t mm = __ballot(hbits != 0);
+                        if (!mm) break;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&S.qn, (uint32_t)__popcll(mm));
+                        base = rfl(base);
+                        if (hbits) {
+                            const int j = __ffs((int)hbits) - 1; hbits &= hbits - 1u;
+                            const int pp = 2 * (ee + j);
+                            const uint32_t wq = pkb + 4u * ((uint32_t)pp >> 4);
+                            const uint32_t cd = __builtin_amdgcn_alignbit(*reinterpret_cast<const uint32_t *>(&S.buf[wq + 4u]),
+                                                                          *reinterpret_cast<const uint32_t *>(&S.buf[wq]), ((uint32_t)pp & 15u) * 2u) & 0xFFFFu;
+                            const uint32_t idx = base + (uint32_t)__popcll(mm & kvq_lanemask_lt());
+                            if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)pp << 16), cd);   // beyond the cap: dropped, the stretch is redone in halves
+                        }
+                    }
+                }
+                // the 2(e+1) fixed head / tail blocks of the read against the index of all sequence positions:
+                // the group's first lane takes the head blocks, its last lane the tail blocks; one push round
+                {
+                    uint32_t fx = 0, fcd[14];                                    // bit 2j: head block j hit, bit 2j+1: tail block j hit
+#pragma unroll
+                    for (int j = 0; j < 14; j++) fcd[j] = 0;
+                    if (mine && (gl == 0 || gl == G - 1u)) {
+#pragma unroll
+                        for (int j = 0; j < 7; j++) {
+                            if (j <= P.maxerrors) {
+#pragma unroll
+                                for (int side = 0; side < 2; side++) {
+                                    const int pp = side == 0 ? j * SK : rl - (j + 1) * SK;
+                                    const bool my = side == 0 ? gl == 0 : gl == G - 1u;
+                                    const bool dup = side == 1 && (pp % SK) == 0 && pp <= P.maxerrors * SK;   // a tail block that is also a head block
+                                    if (my && !dup && pp >= 0 && pp + SK <= rl) {
+                                        const uint32_t wq = pkb + 4u * ((uint32_t)pp >> 4);
+                                        const uint32_t cd = __builtin_amdgcn_alignbit(*reinterpret_cast<const uint32_t *>(&S.buf[wq + 4u]),
+                                                                                      *reinterpret_cast<const uint32_t *>(&S.buf[wq]), ((uint32_t)pp & 15u) * 2u) & 0xFFFFu;
+                                        fcd[2 * j + side] = cd | ((uint32_t)pp << 16);
+                                        fx |= ((S.bm2[cd >> 4] >> (((cd & 15u) << 1) + 1u)) & 1u) << (2 * j + side);
+                                    }
+                                }
                             }
                         }
-                        uint64_t h = h64 & keep;
-                        for (;;) {
-                            const uint64_t mm = __ballot(h != 0);
-                            if (!mm) break;
-                            // one LDS atomic per wave and round; the code comes back out of the packed words
-                            uint32_t base = 0;
-                            if (lane == 0) base = atomicAdd(&S.qn, (uint32_t)__popcll(mm));
-                            base = rfl(base);
-                            if (h) {
-                                const int bit = __ffsll((long long)h) - 1; h &= h - 1ull;
-                                const int pp = c0 + (bit >> 1);
-                                const uint32_t kind = (uint32_t)(bit & 1);
-                                const uint32_t wq = pkb + 4u * ((uint32_t)pp >> 4);
-                                const uint32_t cd = __builtin_amdgcn_alignbit(*reinterpret_cast<const uint32_t *>(&S.buf[wq + 4u]),
-                                                                              *reinterpret_cast<const uint32_t *>(&S.buf[wq]), ((uint32_t)pp & 15u) * 2u) & 0xFFFFu;
-                                const uint32_t idx = base + (uint32_t)__popcll(mm & kvq_lanemask_lt());
-                                if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)pp << 16), cd | (kind << 16));   // beyond the cap: dropped, the stretch is redone in halves
-                            }
+                    }
+                    for (;;) {
+                        const uint64_t mm = __ballot(fx != 0);
+                        if (!mm) break;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&S.qn, (uint32_t)__popcll(mm));
+                        base = rfl(base);
+                        if (fx) {
+                            const int b2 = __ffs((int)fx) - 1; fx &= fx - 1u;
+                            uint32_t v = 0;
+#pragma unroll
+                            for (int t = 0; t < 14; t++) v = b2 == t ? fcd[t] : v;
+                            const uint32_t idx = base + (uint32_t)__popcll(mm & kvq_lanemask_lt());
+                            if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | (v & 0xFFFF0000u), (v & 0xFFFFu) | (1u << 16));
                         }
                     }
                 }
@@ -781,10 +824,11 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     SeedIndex *ix = s->t->index;
     // tiles per chunk; the tables live in the scan's pool so that nothing here waits for the GPU
     const std::vector<int64_t> &co = s->cur_chunk_off;
+    const uint32_t TILE = ix->variant ? kvq_planes_tile_bytes() : ST_TILE;
     uint64_t nt = 0;
     for (int64_t c = 0; c < nchunks; c++) {
         const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
-        nt += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + ST_TILE - 1) / ST_TILE) : 0u;
+        nt += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
     }
     if (nt == 0) return KVQ_OK;
     int rc;
@@ -796,7 +840,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     for (int64_t c = 0; c < nchunks; c++) {
         const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
         first[c] = (uint32_t)acc;
-        acc += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + ST_TILE - 1) / ST_TILE) : 0u;
+        acc += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
     }
     first[nchunks] = (uint32_t)acc;
     uint32_t *d_first = reinterpret_cast<uint32_t *>(s->pool.d + first_at);
@@ -808,12 +852,19 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     static bool attr_set = false;
     if (!attr_set) {
         KVQ_HIP(hipFuncSetAttribute((const void *)kvq_scan_seeded, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
+        KVQ_HIP(hipFuncSetAttribute((const void *)kvq_scan_planes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kvq_planes_lds_bytes()));
         attr_set = true;
     }
     static const uint32_t dbg = (uint32_t)(getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, 512);
-    hipLaunchKernelGGL(kvq_scan_seeded, dim3(grid), dim3(ST_THREADS), sizeof(SeededLds), s->stream, P, ix->dev, d_data, fpos_base,
-                       d_chunk_off, d_tchunk, d_first, (uint32_t)nt, d_report, dbg);
+    if (ix->variant) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, 768);               // up to three workgroups per CU
+        hipLaunchKernelGGL(kvq_scan_planes, dim3(grid), dim3(512), kvq_planes_lds_bytes(), s->stream, P, ix->dev, d_data, fpos_base,
+                           d_chunk_off, d_tchunk, d_first, (uint32_t)nt, d_report, dbg);
+    } else {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, 512);
+        hipLaunchKernelGGL(kvq_scan_seeded, dim3(grid), dim3(ST_THREADS), sizeof(SeededLds), s->stream, P, ix->dev, d_data, fpos_base,
+                           d_chunk_off, d_tchunk, d_first, (uint32_t)nt, d_report, dbg);
+    }
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                        d_first, d_report, s->cur_fail);
     KVQ_HIP(hipGetLastError());

@@ -433,7 +433,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
                            (const unsigned int *)(s->d_fail + batch_no), s->d_arena_n, (const unsigned int *)(s->d_range + batch_no));
     // hits of this batch = arena[range[batch_no], range[batch_no + 1])
     KVQ_HIP(hipMemcpyAsync(s->d_range + batch_no + 1, s->d_arena_n, 4, hipMemcpyDeviceToDevice, s->stream));
-    hipLaunchKernelGGL(kvq_fold_hits, dim3(64), dim3(256), 0, s->stream, P, d_data, fpos_base,
+    hipLaunchKernelGGL(kvq_fold_hits, dim3(512), dim3(256), 0, s->stream, P, d_data, fpos_base,
                        (const unsigned int *)(s->d_range + batch_no), (const unsigned int *)(s->d_range + batch_no + 1));
     KVQ_HIP(hipEventRecord(s->ev_all.back().second, s->stream));
     KVQ_HIP(hipGetLastError());

@@ -2,6 +2,7 @@
 // must share one HIP module)
 #include "kernels_general.hip"
 #include "kernels_seeded.hip"
+#include "kernels_planes.hip"
 #include "synth.hip"
 #include "kvq_runtime.hip"
 #include "kvq_findseqs.hip"
