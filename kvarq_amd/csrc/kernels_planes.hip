@@ -53,10 +53,10 @@ struct PTile {
 
 __device__ __forceinline__ PTile ptile(uint32_t g, const uint32_t *chunk_off, const uint32_t *tile_chunk, const uint32_t *tile_first)
 {
+    (void)chunk_off; (void)tile_first;
     PTile J;
-    const uint32_t c = tile_chunk[g];
-    J.a = chunk_off[c]; J.b = chunk_off[c + 1];
-    J.t = g - tile_first[c];
+    const uint4 q = reinterpret_cast<const uint4 *>(tile_chunk)[g];     // the per-tile table of kvq_expand_tiles
+    J.a = q.x; J.b = q.y; J.t = q.z;
     J.g0 = (J.a & ~15u) + J.t * PT_TILE;
     J.own_end = J.g0 + PT_TILE < J.b ? J.g0 + PT_TILE : J.b;
     J.own_begin = J.t == 0 ? J.a : J.g0;
@@ -230,10 +230,8 @@ kvq_scan_planes(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
             uint32_t n = mine + incl - cnt;
             {
                 // owned newlines: one LDS atomic per wave
-                uint32_t o = blk < own_end_w ? cnt : 0u;
-#pragma unroll
-                for (int dd = 32; dd >= 1; dd >>= 1) o += __shfl_xor(o, dd, 64);
-                if (lane == 0 && o) atomicAdd(&S.n_owned, o);
+                const uint32_t o = kvq_wave_incl_scan(blk < own_end_w ? cnt : 0u);
+                if (lane == 63 && o) atomicAdd(&S.n_owned, o);
             }
             uint64_t nm = (uint64_t)nlo | ((uint64_t)nhi << 32);
             while (nm) {

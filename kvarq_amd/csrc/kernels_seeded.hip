@@ -176,10 +176,11 @@ struct TileGeo {
 
 __device__ __forceinline__ TileGeo tile_geo(uint32_t g, const uint32_t *chunk_off, const uint32_t *tile_chunk, const uint32_t *tile_first)
 {
+    // tile_chunk is the per-tile table kvq_expand_tiles wrote: {chunk begin, chunk end, tile number, -}
+    (void)chunk_off; (void)tile_first;
     TileGeo J;
-    const uint32_t c = tile_chunk[g];
-    J.a = chunk_off[c]; J.b = chunk_off[c + 1];
-    J.t = g - tile_first[c];
+    const uint4 q = reinterpret_cast<const uint4 *>(tile_chunk)[g];
+    J.a = q.x; J.b = q.y; J.t = q.z;
     J.g0 = (J.a & ~15u) + J.t * ST_TILE;
     J.own_end = J.g0 + ST_TILE < J.b ? J.g0 + ST_TILE : J.b;
     J.own_begin = J.t == 0 ? J.a : J.g0;
@@ -298,6 +299,14 @@ __device__ __forceinline__ void verify_item(const KvqParams &P, const SeededLds 
         if ((canAB || canC) && L > 0) {
             int mism = 0, j = 0;
             const uint32_t x = roff + (uint32_t)a; const uint8_t *y = seq + a + d;
+            if (L >= 16) {                                           // most false candidates die here, after one round trip
+                uint32_t rw[4], sw[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) { __builtin_memcpy(&rw[t], &S.buf[x + 4 * t], 4); __builtin_memcpy(&sw[t], y + 4 * t, 4); }
+#pragma unroll
+                for (int t = 0; t < 4; t++) mism += diff_bytes(rw[t], sw[t]);
+                j = 16;
+            }
             for (; j + 4 <= L && mism <= me; j += 4) {
                 uint32_t rw, sw;
                 __builtin_memcpy(&rw, &S.buf[x + j], 4); __builtin_memcpy(&sw, y + j, 4);
@@ -425,10 +434,8 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
         if (lane == 63) S.wtot[wave] = incl;
         {
             // owned newlines: one LDS atomic per wave
-            uint32_t o = cnt_owned;
-#pragma unroll
-            for (int dd = 32; dd >= 1; dd >>= 1) o += __shfl_xor(o, dd, 64);
-            if (lane == 0 && o) atomicAdd(&S.n_owned, o);
+            const uint32_t o = kvq_wave_incl_scan(cnt_owned);
+            if (lane == 63 && o) atomicAdd(&S.n_owned, o);
         }
         if (tid == 0) { S.qn = 0; S.q2n = 0; }
         __syncthreads();
@@ -808,13 +815,14 @@ kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, co
 // launch
 // ---------------------------------------------------------------------------
 
-// one thread per chunk: tile_chunk[g] = chunk of tile g
+// one thread per chunk: per-tile table {chunk begin, chunk end, tile number inside the chunk, chunk}
 extern "C" __global__ void __launch_bounds__(256)
-kvq_expand_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, uint32_t *__restrict__ tile_chunk)
+kvq_expand_tiles(uint32_t nchunks, const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ tile_first, uint4 *__restrict__ tile_tab)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
-    for (uint32_t g = tile_first[c]; g < tile_first[c + 1]; g++) tile_chunk[g] = c;
+    const uint32_t a = chunk_off[c], b = chunk_off[c + 1], g0 = tile_first[c];
+    for (uint32_t g = g0; g < tile_first[c + 1]; g++) tile_tab[g] = make_uint4(a, b, g - g0, c);
 }
 
 int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
@@ -832,9 +840,9 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     }
     if (nt == 0) return KVQ_OK;
     int rc;
-    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 4 + (size_t)nt * 8 + 4096, s->stream))) return rc;
+    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 4096, s->stream))) return rc;
     const size_t first_at = s->pool.take(((size_t)nchunks + 1) * 4);
-    const size_t chunk_at = s->pool.take((size_t)nt * 4), report_at = s->pool.take((size_t)nt * 4);
+    const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 4);
     uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
     uint64_t acc = 0;
     for (int64_t c = 0; c < nchunks; c++) {
@@ -847,7 +855,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
     uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
     KVQ_HIP(hipMemcpyAsync(d_first, first, ((size_t)nchunks + 1) * 4, hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_first, d_tchunk);
+    hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
 
     static bool attr_set = false;
     if (!attr_set) {

@@ -70,15 +70,16 @@ __device__ __forceinline__ uint32_t kvq_range_flags(uint32_t p, uint32_t a, uint
     return (uint32_t)m & 0x80808080u;
 }
 
-// inclusive prefix sum over the 64 lanes of a wave
+// inclusive prefix sum over the 64 lanes of a wave, all lanes active: six DPP adds
+// (row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast 15 and 31 across rows), no LDS traffic
 __device__ __forceinline__ uint32_t kvq_wave_incl_scan(uint32_t v)
 {
-    const int lane = kvq_lane();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
     return v;
 }
 
