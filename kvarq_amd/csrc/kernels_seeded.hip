@@ -338,6 +338,17 @@ __device__ __forceinline__ void verify_item(const KvqParams &P, const SeededLds 
     kvq_emit(P, hitC, fpos, s, sposC, lenC, rl, keyC);
 }
 
+// 16 bytes of batch text at the 16-aligned offset gp, zeros at and behind the vector that holds
+// byte hi - 1: a raw buffer load whose range check replaces the branch (no exec masking, so the
+// loads of a tile go out back to back).  The batch buffer is padded to a multiple of 16.
+__device__ __forceinline__ uint4 text_load16(const uint8_t *data, uint32_t gp, uint32_t hi)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)data, 0, (int)((hi + 15u) & ~15u), 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gp, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ uint32_t bits8_at(uint32_t w0, uint32_t w1, uint32_t w2, int lane)
 {
     // bits lane .. lane+7 of the 96-bit string w0 | w1 << 32 | w2 << 64
@@ -370,7 +381,7 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
 #pragma unroll
         for (int r = 0; r < (int)ST_ROUNDS; r++) {
             const uint32_t gp = J.load_lo + (uint32_t)(r * ST_THREADS + tid) * 16u;
-            pre[r] = gp < J.load_hi ? *reinterpret_cast<const uint4 *>(data + gp) : make_uint4(0, 0, 0, 0);
+            pre[r] = text_load16(data, gp, J.load_hi);
         }
     }
     __syncthreads();
@@ -378,6 +389,9 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
     for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
         const TileGeo J = tile_geo(g, chunk_off, tile_chunk, tile_first);
         if (dbg & 16u) stamp_t = __builtin_amdgcn_s_memtime();
+        // every vector load has to be back here anyway; saying so on all paths keeps the
+        // compiler from waiting for the next tile's loads in the middle of this tile
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0)
 
         // ---- P0: registers -> LDS (coalesced order); the next tile's loads go out ----
         // bytes in front of the chunk start and behind the loaded text are zeroed here (at most
@@ -405,7 +419,7 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
 #pragma unroll
             for (int r = 0; r < (int)ST_ROUNDS; r++) {
                 const uint32_t gp = N.load_lo + (uint32_t)(r * ST_THREADS + tid) * 16u;
-                pre[r] = gp < N.load_hi ? *reinterpret_cast<const uint4 *>(data + gp) : make_uint4(0, 0, 0, 0);
+                pre[r] = text_load16(data, gp, N.load_hi);
             }
         }
         if (tid == 0) { S.n_owned = 0; S.fallback = 0; }

@@ -56,6 +56,11 @@ struct kvq_table {
     int64_t ctr_len, off_nseqhits, off_nseqbasehits, off_cov, off_mut;
 };
 
+// where each array of a finished scan lives inside the result buffer (device copy and pinned host copy alike)
+struct KvqResultLayout {
+    size_t file_pos = 0, hitseq_off = 0, seq_nr = 0, seq_pos = 0, length = 0, readlength = 0, blob = 0, total = 0;
+};
+
 struct Batch {
     const uint8_t *d_data; int64_t nbytes; int64_t fpos_base;
     std::vector<int64_t> chunk_off;
@@ -90,11 +95,12 @@ struct kvq_scan {
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_all, ev_main;
     double ms_all = 0, ms_main = 0; int64_t main_launches = 0;
-    // results on the host
-    uint8_t *pin = nullptr; size_t pin_cap = 0;   // pinned landing buffer of finish
-    std::vector<int32_t> r_seq_nr, r_seq_pos, r_length, r_readlength;
-    std::vector<int64_t> r_file_pos, r_hitseq_off;
-    std::vector<uint8_t> r_blob;
+    // results: ordered and laid out on the device (kernels_results.hip), one copy into pinned host memory
+    DevBuf d_sort_tmp, d_sorted, d_result;
+    uint8_t *pin = nullptr; size_t pin_cap = 0;   // pinned landing buffer of finish: the result arrays, then the counters
+    uint8_t *pin_small = nullptr;                 // pinned landing buffer for the scan's small words and fail flags
+    KvqResultLayout res;                          // where the arrays sit inside pin
+    uint64_t n_hits = 0;
     bool finished = false;
 };
 

@@ -253,6 +253,13 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     s->d_fail = (unsigned int *)((char *)s->d_small.p + SMALL_FAIL);
     s->d_stage_ctr = (unsigned long long *)((char *)s->d_small.p + SMALL_STAGE);
     if (ensure_arena(s, 1u << 20, 64ull << 20) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
+    s->pin_cap = (size_t)t->ctr_len * 8 + (4u << 20);
+    if (hipHostMalloc((void **)&s->pin_small, 64 + 4 * (size_t)KVQ_MAX_BATCHES, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&s->pin, s->pin_cap, hipHostMallocDefault) != hipSuccess) {
+        kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); kvq_scan_destroy(s); return nullptr;
+    }
+    memset(s->pin, 0, 4096);
+    s->res = kvq_result_layout(0, 0);
     if (reset_device_state(s) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     s->h_ctr.assign((size_t)t->ctr_len, 0);
     return s;
@@ -272,7 +279,8 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     drop_events(s);
     if (s->own_ctr && s->d_ctr) (void)hipFree(s->d_ctr);
     if (s->pin) (void)hipHostFree(s->pin);
-    DevBuf *bufs[] = { &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
+    if (s->pin_small) (void)hipHostFree(s->pin_small);
+    DevBuf *bufs[] = { &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
                        &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
     for (DevBuf *b : bufs) b->release();
     s->pool.release();
@@ -290,7 +298,7 @@ extern "C" int32_t kvq_scan_reset(kvq_scan *s)
     KVQ_HIP(hipStreamSynchronize(s->stream));
     drop_events(s);
     s->batches.clear(); s->host_batches = false; s->records = 0; s->parsed = 0; s->total = 0;
-    s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->path_bits = 0;
+    s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->path_bits = 0; s->n_hits = 0;
     s->pool.used = 0;
     const int rr = reset_device_state(s);
     if (g_timing) fprintf(stderr, "reset host %.3f ms\n", now_ms() - tr0);
@@ -482,31 +490,37 @@ extern "C" int32_t kvq_scan_host(kvq_scan *s, const void *h_data, int64_t nbytes
 static int finish_once(kvq_scan *s)
 {
     const double t0 = now_ms();
-    KVQ_HIP(hipStreamSynchronize(s->stream));
+    // the scan's small words (hit count, hit bytes, first error) and the per-batch "speculation
+    // failed" flags arrive behind everything that is enqueued: one wait for all of it
+    const size_t nb0 = s->batches.size();
+    unsigned char *small = s->pin_small; unsigned int *fail = reinterpret_cast<unsigned int *>(s->pin_small + 64);
+    auto fetch_small = [&]() -> int {
+        KVQ_HIP(hipMemcpyAsync(small, s->d_small.p, 32, hipMemcpyDeviceToHost, s->stream));
+        if (!s->batches.empty()) KVQ_HIP(hipMemcpyAsync(fail, s->d_fail, s->batches.size() * 4, hipMemcpyDeviceToHost, s->stream));
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        return KVQ_OK;
+    };
+    int rc;
+    if ((rc = fetch_small())) return rc;
     const double t1 = now_ms();
     // batches whose seed-filter pass failed validation (a tile's speculated record split
     // disagreed with the newline count, or a record outgrew the tile look-ahead) were rolled
     // back on the device: scan those again with the exhaustive kernels (device batches only;
     // host batches were redone on the spot)
-    if (!s->batches.empty() && (s->path_bits & 1)) {
-        std::vector<unsigned int> fail(s->batches.size());
-        KVQ_HIP(hipMemcpy(fail.data(), s->d_fail, fail.size() * 4, hipMemcpyDeviceToHost));
+    if (nb0 && (s->path_bits & 1)) {
         bool any = false;
-        const size_t nb = s->batches.size();
-        for (size_t b = 0; b < nb; b++) {
+        for (size_t b = 0; b < nb0; b++) {
             if (!fail[b] || s->batches[b].redone || !s->batches[b].d_data) continue;
             s->batches[b].redone = true;
             Batch again = s->batches[b]; again.is_redo = true;
             s->batches.push_back(again);
             s->path_bits |= 4; any = true;
-            int rc = run_batch(s, again.d_data, again.nbytes, again.chunk_off.data(), (int64_t)again.chunk_off.size() - 1,
-                               again.fpos_base, s->batches.size() - 1, true);
+            rc = run_batch(s, again.d_data, again.nbytes, again.chunk_off.data(), (int64_t)again.chunk_off.size() - 1,
+                           again.fpos_base, s->batches.size() - 1, true);
             if (rc) return rc;
         }
-        if (any) KVQ_HIP(hipStreamSynchronize(s->stream));
+        if (any && (rc = fetch_small())) return rc;
     }
-    unsigned char small[32];
-    KVQ_HIP(hipMemcpy(small, s->d_small.p, 32, hipMemcpyDeviceToHost));
     unsigned int n_hits; unsigned long long blob_n, err;
     memcpy(&n_hits, small, 4); memcpy(&blob_n, small + 8, 8); memcpy(&err, small + 16, 8);
     if (err != ~0ull) {
@@ -523,69 +537,35 @@ static int finish_once(kvq_scan *s)
         uint64_t want_blob = blob_n;
         if (n_hits > s->arena_cap && s->arena_cap) want_blob = (uint64_t)((double)blob_n * ((double)n_hits / s->arena_cap) * 1.25) + (1 << 20);
         want_blob = std::max<uint64_t>(want_blob + want_blob / 8, s->blob_cap);
-        int rc = ensure_arena(s, want_hits, want_blob); if (rc) return rc;
+        rc = ensure_arena(s, want_hits, want_blob); if (rc) return rc;
         return KVQ_NEED_RESCAN;
     }
-    // results to the host
-    // one pinned host buffer takes hits, hit bytes and counters in three async copies
-    const size_t hits_b = ((size_t)n_hits * sizeof(KvqHit) + 255) & ~(size_t)255, blob_b = ((size_t)blob_n + 255) & ~(size_t)255;
+    // results: put into canonical order and into their final arrays on the device
+    // (kernels_results.hip), then one pinned host buffer takes the arrays and the counters
+    const KvqResultLayout L = kvq_result_layout(n_hits, blob_n);
     const size_t ctr_b = (size_t)s->t->ctr_len * 8;
-    if (hits_b + blob_b + ctr_b > s->pin_cap) {
+    if (L.total + ctr_b > s->pin_cap) {
         if (s->pin) (void)hipHostFree(s->pin);
         s->pin = nullptr; s->pin_cap = 0;
-        const size_t want = (hits_b + blob_b + ctr_b) * 5 / 4 + (1 << 20);
+        const size_t want = (L.total + ctr_b) * 5 / 4 + (1 << 20);
         if (hipHostMalloc((void **)&s->pin, want, hipHostMallocDefault) != hipSuccess) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); return KVQ_ERR_MEMORY; }
         s->pin_cap = want;
     }
-    const KvqHit *hits = reinterpret_cast<const KvqHit *>(s->pin);
-    const uint8_t *blob = s->pin + hits_b;
-    if (n_hits) KVQ_HIP(hipMemcpyAsync(s->pin, s->d_arena.p, (size_t)n_hits * sizeof(KvqHit), hipMemcpyDeviceToHost, s->stream));
-    if (blob_n) KVQ_HIP(hipMemcpyAsync(s->pin + hits_b, s->d_blob.p, (size_t)blob_n, hipMemcpyDeviceToHost, s->stream));
-    KVQ_HIP(hipMemcpyAsync(s->pin + hits_b + blob_b, s->d_ctr, ctr_b, hipMemcpyDeviceToHost, s->stream));
+    if ((rc = s->d_result.ensure(L.total + 256))) return rc;
+    if ((rc = kvq_order_results(s->stream, s->d_arena.as<KvqHit>(), n_hits, s->d_blob.as<uint8_t>(), s->d_sort_tmp, s->d_sorted,
+                                s->d_result.as<uint8_t>(), L))) return rc;
+    if (n_hits) KVQ_HIP(hipMemcpyAsync(s->pin, s->d_result.p, L.total, hipMemcpyDeviceToHost, s->stream));
+    KVQ_HIP(hipMemcpyAsync(s->pin + L.total, s->d_ctr, ctr_b, hipMemcpyDeviceToHost, s->stream));
     KVQ_HIP(hipStreamSynchronize(s->stream));
-    memcpy(s->h_ctr.data(), s->pin + hits_b + blob_b, ctr_b);
-
-    const double t2 = now_ms();
-    // canonical order (file_pos, seq_nr, class/ordinal): hits spread evenly over file_pos, so a
-    // counting sort into file_pos buckets followed by tiny in-bucket sorts is linear
-    std::vector<uint32_t> order(n_hits);
-    if (n_hits) {
-        int64_t lo = hits[0].fpos, hi = hits[0].fpos;
-        for (uint32_t i = 1; i < n_hits; i++) { lo = std::min(lo, hits[i].fpos); hi = std::max(hi, hits[i].fpos); }
-        uint32_t nb = 1; while (nb < n_hits / 2 && nb < (1u << 22)) nb <<= 1;
-        const double scale = (double)nb / ((double)(hi - lo) + 1.0);
-        std::vector<uint32_t> start((size_t)nb + 1, 0), bucket(n_hits);
-        for (uint32_t i = 0; i < n_hits; i++) { bucket[i] = (uint32_t)((double)(hits[i].fpos - lo) * scale); if (bucket[i] >= nb) bucket[i] = nb - 1; start[bucket[i] + 1]++; }
-        for (uint32_t b = 0; b < nb; b++) start[b + 1] += start[b];
-        std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-        for (uint32_t i = 0; i < n_hits; i++) order[fill[bucket[i]]++] = i;
-        auto less = [&](uint32_t x, uint32_t y) {
-            const KvqHit &a = hits[x], &b = hits[y];
-            if (a.fpos != b.fpos) return a.fpos < b.fpos;
-            if (a.seq_nr != b.seq_nr) return a.seq_nr < b.seq_nr;
-            return a.key < b.key;
-        };
-        for (uint32_t b = 0; b < nb; b++)
-            if (start[b + 1] - start[b] > 1) std::sort(order.begin() + start[b], order.begin() + start[b + 1], less);
-    }
-    const double t3 = now_ms();
-    s->r_seq_nr.resize(n_hits); s->r_seq_pos.resize(n_hits); s->r_length.resize(n_hits); s->r_readlength.resize(n_hits);
-    s->r_file_pos.resize(n_hits); s->r_hitseq_off.resize((size_t)n_hits + 1); s->r_blob.resize((size_t)blob_n);
-    int64_t at = 0;
-    for (uint32_t i = 0; i < n_hits; i++) {
-        const KvqHit &h = hits[order[i]];
-        s->r_seq_nr[i] = h.seq_nr; s->r_file_pos[i] = h.fpos; s->r_seq_pos[i] = h.seq_pos; s->r_length[i] = h.length; s->r_readlength[i] = h.readlength;
-        s->r_hitseq_off[i] = at;
-        if (h.length > 0) memcpy(&s->r_blob[(size_t)at], blob + h.blob_off, (size_t)h.length);
-        at += h.length;
-    }
-    s->r_hitseq_off[n_hits] = at;
+    memcpy(s->h_ctr.data(), s->pin + L.total, ctr_b);
+    if (!n_hits) memset(s->pin + L.hitseq_off, 0, 8);
+    s->res = L; s->n_hits = n_hits;
 
     s->ms_all = s->ms_main = 0;
     for (auto &e : s->ev_all) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_all += ms; }
     for (auto &e : s->ev_main) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_main += ms; }
     s->finished = true;
-    if (g_timing) fprintf(stderr, "finish: wait %.3f  d2h %.3f  sort %.3f  build %.3f ms (%u hits)\n", t1 - t0, t2 - t1, t3 - t2, now_ms() - t3, n_hits);
+    if (g_timing) fprintf(stderr, "finish: wait %.3f  order + d2h %.3f ms (%u hits)\n", t1 - t0, now_ms() - t1, n_hits);
     return KVQ_OK;
 }
 
@@ -621,14 +601,14 @@ extern "C" int32_t kvq_scan_finish(kvq_scan *s)
     return rc;
 }
 
-extern "C" int64_t kvq_scan_n_hits(const kvq_scan *s) { return (int64_t)s->r_seq_nr.size(); }
-extern "C" const int32_t *kvq_scan_hit_seq_nr(const kvq_scan *s) { return s->r_seq_nr.data(); }
-extern "C" const int64_t *kvq_scan_hit_file_pos(const kvq_scan *s) { return s->r_file_pos.data(); }
-extern "C" const int32_t *kvq_scan_hit_seq_pos(const kvq_scan *s) { return s->r_seq_pos.data(); }
-extern "C" const int32_t *kvq_scan_hit_length(const kvq_scan *s) { return s->r_length.data(); }
-extern "C" const int32_t *kvq_scan_hit_readlength(const kvq_scan *s) { return s->r_readlength.data(); }
-extern "C" const uint8_t *kvq_scan_hitseq_blob(const kvq_scan *s) { return s->r_blob.data(); }
-extern "C" const int64_t *kvq_scan_hitseq_offsets(const kvq_scan *s) { return s->r_hitseq_off.data(); }
+extern "C" int64_t kvq_scan_n_hits(const kvq_scan *s) { return (int64_t)s->n_hits; }
+extern "C" const int32_t *kvq_scan_hit_seq_nr(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin + s->res.seq_nr); }
+extern "C" const int64_t *kvq_scan_hit_file_pos(const kvq_scan *s) { return reinterpret_cast<const int64_t *>(s->pin + s->res.file_pos); }
+extern "C" const int32_t *kvq_scan_hit_seq_pos(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin + s->res.seq_pos); }
+extern "C" const int32_t *kvq_scan_hit_length(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin + s->res.length); }
+extern "C" const int32_t *kvq_scan_hit_readlength(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin + s->res.readlength); }
+extern "C" const uint8_t *kvq_scan_hitseq_blob(const kvq_scan *s) { return s->pin + s->res.blob; }
+extern "C" const int64_t *kvq_scan_hitseq_offsets(const kvq_scan *s) { return reinterpret_cast<const int64_t *>(s->pin + s->res.hitseq_off); }
 extern "C" const int64_t *kvq_scan_counters(const kvq_scan *s) { return s->h_ctr.data(); }
 extern "C" void *kvq_scan_device_counters(const kvq_scan *s) { return s->d_ctr; }
 extern "C" int64_t kvq_scan_parsed(const kvq_scan *s) { return s->parsed; }

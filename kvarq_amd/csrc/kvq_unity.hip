@@ -3,6 +3,7 @@
 #include "kernels_general.hip"
 #include "kernels_seeded.hip"
 #include "kernels_planes.hip"
+#include "kernels_results.hip"
 #include "synth.hip"
 #include "kvq_runtime.hip"
 #include "kvq_findseqs.hip"
