@@ -54,6 +54,7 @@ struct SeedTables {
     const uint32_t *start_anc, *start_all;    // CSR starts, 65537 entries
     // entry: position in sequence (12) | sequence number (20) | table offset of the sequence (20) | its length (12)
     const uint64_t *ent_anc, *ent_all;
+    int32_t stride;                           // read positions 0, stride, 2*stride, ... are looked up for anchors (2, 4 or 8)
 };
 
 // the planes kernel (kernels_planes.hip)
@@ -65,6 +66,7 @@ uint32_t kvq_planes_tile_bytes();
 
 struct SeedIndex {
     int variant = 0;          // 0 = kvq_scan_seeded, 1 = kvq_scan_planes (KVQ_KERNEL=planes)
+    int stride = 2;           // anchor blocks sit at sequence offsets 8j + 0 .. 8j + stride - 1
     DevBuf d_bm2, d_start_anc, d_start_all, d_ent_anc, d_ent_all;
     SeedTables dev;
 };
@@ -92,17 +94,26 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     // are >= minoverlap, class C lengths are min(readlength, sequence length)
     if (cfg.minoverlap < need || cfg.minreadlength < need) return nullptr;
     if (cfg.Amin <= 13) return nullptr;          // the kernel relies on '\n' and '\r' closing every quality run (1058)
+    int minlen = 1 << 30;
     for (int s = 0; s < t->nseq; s++) {
         const int len = t->h_off[s + 1] - t->h_off[s];
-        bool ok = len >= need + 1 && len <= 4095 && t->h_off[s] < (1 << 20) && s < (1 << 20);   // the shifted anchor set needs one more base
+        bool ok = len >= need + 1 && len <= 4095 && t->h_off[s] < (1 << 20) && s < (1 << 20);   // the shifted anchor sets need stride - 1 more bases
         for (int i = 0; ok && i < len; i++) {
             const uint8_t c = t->h_tab[t->h_off[s] + i];
             ok = (c == 'A' || c == 'C' || c == 'G' || c == 'T');
         }
-        if (ok) { t->seeded.push_back(s); t->is_seeded[s] = 1; }
+        if (ok) { t->seeded.push_back(s); t->is_seeded[s] = 1; minlen = std::min(minlen, len); }
     }
     if (t->seeded.empty()) return nullptr;
     t->seed_k = SK;
+    // a sequence contained in a read at offset d is met through the anchor block at sequence
+    // offset 8j + sft with sft = -d mod stride, at a read position that is a multiple of the
+    // stride: the wider the stride the fewer lookups per read (and the more index entries per
+    // sequence -- the expected number of candidates stays the same).  Every seeded sequence
+    // must be able to hold its shifted blocks: length >= 8(e+1) + stride - 1.
+    int stride = minlen >= need + 7 ? 8 : minlen >= need + 3 ? 4 : 2;
+    if (const char *sv = getenv("KVQ_STRIDE")) { const int w = atoi(sv); if ((w == 2 || w == 4 || w == 8) && w <= stride) stride = w; }
+    if (variant == 1) stride = 2;                               // the planes kernel looks up every even position
 
     std::vector<std::pair<uint32_t, uint64_t>> anc, all;       // (code, entry)
     for (int s : t->seeded) {
@@ -110,11 +121,11 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
         const int len = t->h_off[s + 1] - t->h_off[s];
         const uint64_t hi = ((uint64_t)(uint32_t)t->h_off[s] << 32) | ((uint64_t)(uint32_t)len << 52) | ((uint64_t)(uint32_t)s << 12);
         for (int j = 0; j <= e; j++)
-            for (int sft = 0; sft <= 1; sft++) anc.emplace_back(host_code8(q + j * SK + sft), hi | (uint64_t)(j * SK + sft));
+            for (int sft = 0; sft < stride; sft++) anc.emplace_back(host_code8(q + j * SK + sft), hi | (uint64_t)(j * SK + sft));
         for (int p = 0; p + SK <= len; p++) all.emplace_back(host_code8(q + p), hi | (uint64_t)p);
     }
     SeedIndex *ix = new SeedIndex();
-    ix->variant = variant;
+    ix->variant = variant; ix->stride = stride;
     std::vector<uint32_t> bm2(4096, 0);
     auto upload = [&](std::vector<std::pair<uint32_t, uint64_t>> &v, int bit, DevBuf &st, DevBuf &en) -> bool {
         std::sort(v.begin(), v.end());
@@ -134,6 +145,7 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     ix->dev.bm2 = ix->d_bm2.as<uint32_t>();
     ix->dev.start_anc = ix->d_start_anc.as<uint32_t>(); ix->dev.start_all = ix->d_start_all.as<uint32_t>();
     ix->dev.ent_anc = ix->d_ent_anc.as<uint64_t>(); ix->dev.ent_all = ix->d_ent_all.as<uint64_t>();
+    ix->dev.stride = stride;
     return ix;
 }
 
@@ -174,12 +186,11 @@ struct TileGeo {
     uint32_t load_lo, load_hi, lds_lo;   // loaded byte range [load_lo, load_hi) lands at buf[lds_lo ...]
 };
 
-__device__ __forceinline__ TileGeo tile_geo(uint32_t g, const uint32_t *chunk_off, const uint32_t *tile_chunk, const uint32_t *tile_first)
+__device__ __forceinline__ TileGeo tile_geo(uint32_t g, const uint4 *tiles)
 {
-    // tile_chunk is the per-tile table kvq_expand_tiles wrote: {chunk begin, chunk end, tile number, -}
-    (void)chunk_off; (void)tile_first;
+    // the per-tile table kvq_expand_tiles wrote: {chunk begin, chunk end, tile number, chunk}
     TileGeo J;
-    const uint4 q = reinterpret_cast<const uint4 *>(tile_chunk)[g];
+    const uint4 q = tiles[g];
     J.a = q.x; J.b = q.y; J.t = q.z;
     J.g0 = (J.a & ~15u) + J.t * ST_TILE;
     J.own_end = J.g0 + ST_TILE < J.b ? J.g0 + ST_TILE : J.b;
@@ -190,19 +201,27 @@ __device__ __forceinline__ TileGeo tile_geo(uint32_t g, const uint32_t *chunk_of
     return J;
 }
 
-__device__ __forceinline__ uint32_t lds_code8(const SeededLds &S, uint32_t off)
+// eight text bytes as two dwords -> twice their 16-bit seed code (the byte-wise dot product
+// gathers the 2-bit base codes: bits 1..2 of every byte, weights 1, 4, 16, 64)
+__device__ __forceinline__ uint32_t code8x2_of(uint32_t lo, uint32_t hi)
 {
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < SK; i++) c |= code2_of(S.buf[off + i]) << (2 * i);
-    return c;
+    return __builtin_amdgcn_udot4(lo & 0x06060606u, 0x40100401u, 0u, false) +
+           (__builtin_amdgcn_udot4(hi & 0x06060606u, 0x40100401u, 0u, false) << 8);
 }
+// ... of the 8 bytes at buf[off ...] (any alignment)
+__device__ __forceinline__ uint32_t lds_code8x2(const SeededLds &S, uint32_t off)
+{
+    const uint32_t w = off & ~3u, sh = (off & 3u) * 8u;
+    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(&S.buf[w]), d1 = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u]),
+                   d2 = *reinterpret_cast<const uint32_t *>(&S.buf[w + 8u]);
+    return code8x2_of(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh));
+}
+__device__ __forceinline__ uint32_t lds_code8(const SeededLds &S, uint32_t off) { return lds_code8x2(S, off) >> 1; }
 __device__ __forceinline__ uint32_t glb_code8(const uint8_t *x)
 {
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < SK; i++) c |= code2_of(x[i]) << (2 * i);
-    return c;
+    uint32_t lo, hi;
+    __builtin_memcpy(&lo, x, 4); __builtin_memcpy(&hi, x + 4, 4);
+    return code8x2_of(lo, hi) >> 1;
 }
 
 // 4 score bytes -> 4 bits, bit set = byte is good ((signed) c >= Amin, Amin in 14..127);
@@ -210,7 +229,12 @@ __device__ __forceinline__ uint32_t glb_code8(const uint8_t *x)
 __device__ __forceinline__ uint32_t good4(uint32_t x, uint32_t addk)
 {
     const uint32_t gf = ((x & 0x7F7F7F7Fu) + addk) & ~x & 0x80808080u;    // 0x80 per good byte
-    return (gf * 0x00204081u) >> 28;                                       // bits 7,15,23,31 -> 0..3
+    return __builtin_amdgcn_udot4(gf, 0x08040201u, 0u, false) >> 7;       // bits 7,15,23,31 -> 0..3
+}
+// the same as 0x80 flags per byte
+__device__ __forceinline__ uint32_t good_flags(uint32_t x, uint32_t addk)
+{
+    return ((x & 0x7F7F7F7Fu) + addk) & ~x & 0x80808080u;
 }
 
 // longest run of ones in the low n (1..64) bits of m, first one if several: length, start
@@ -264,8 +288,38 @@ __device__ __forceinline__ int diff_bytes(uint32_t x, uint32_t y)
 // One work item = one (candidate, index entry) pair = one diagonal of one read
 // against one sequence: byte-exact check under the reference's loop bounds and
 // emission of its hits.  Must be called by every lane of the wave.
-__device__ __forceinline__ void verify_item(const KvqParams &P, const SeededLds &S, bool active, uint32_t rec, int p,
-                                            uint32_t kind, uint64_t en, int64_t tile_fpos)
+// the scanning loop keeps only these of KvqParams in scalar registers; the rest is read from
+// the device copy where it is needed (hits, errors, the final flush)
+struct HotParams {
+    const KvqParams *cold;
+    const uint8_t *tab;
+    int maxerrors, minoverlap, minreadlength, amin;
+};
+
+// kvq_emit with the arena words read from the device copy of the parameters, by a wave that has a hit
+__device__ __forceinline__ void emit_cold(const KvqParams *__restrict__ P, bool hit, int64_t fpos, int seq_nr,
+                                          int seq_pos, int length, int rl, uint32_t key)
+{
+    const uint64_t m = __ballot(hit);
+    if (m == 0) return;
+    KvqHit *const arena = P->arena; const uint32_t cap = P->arena_cap; unsigned int *const arena_n = P->arena_n;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (kvq_lane() == leader) base = atomicAdd(arena_n, (unsigned int)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (hit) {
+        const uint32_t idx = base + (uint32_t)__popcll(m & kvq_lanemask_lt());
+        if (idx < cap) {
+            KvqHit h;
+            h.fpos = fpos; h.seq_nr = seq_nr; h.seq_pos = seq_pos; h.length = length;
+            h.readlength = rl; h.key = key; h.blob_off = 0;
+            arena[idx] = h;
+        }
+    }
+}
+
+__device__ __forceinline__ void verify_item(const HotParams &P, const SeededLds &S, bool active, uint32_t rec, int p,
+                                            uint32_t kind, uint64_t en, int64_t tile_fpos, int stride)
 {
     bool hitAB = false, hitC = false;
     int s = 0, rl = 0, lenAB = 0, lenC = 0, sposAB = 0, sposC = 0; uint32_t keyAB = 0, keyC = 0;
@@ -323,19 +377,20 @@ __device__ __forceinline__ void verify_item(const KvqParams &P, const SeededLds 
                     if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live(S, roff, rl, pt, seq, seql, pt + d);
                 }
                 if (kind == 0u) {
-                    // anchors sit at sequence offsets 8j and 8j+1 and are looked up at even read positions only
+                    // anchors sit at sequence offsets 8j + sft (sft < stride) and are looked up at read
+                    // positions that are multiples of the stride only
                     for (int jj = 0; jj <= me && !earlier; jj++)
-                        for (int sft = 0; sft < 2 && !earlier; sft++) {
+                        for (int sft = 0; sft < stride && !earlier; sft++) {
                             const int o = jj * SK + sft;
-                            if (o < q && ((o - d) & 1) == 0) earlier = seed_live(S, roff, rl, o - d, seq, seql, o);
+                            if (o < q && ((o - d) & (stride - 1)) == 0) earlier = seed_live(S, roff, rl, o - d, seq, seql, o);
                         }
                 }
                 if (!earlier) { hitAB = canAB; hitC = canC; }
             }
         }
     }
-    kvq_emit(P, hitAB, fpos, s, sposAB, lenAB, rl, keyAB);
-    kvq_emit(P, hitC, fpos, s, sposC, lenC, rl, keyC);
+    emit_cold(P.cold, hitAB, fpos, s, sposAB, lenAB, rl, keyAB);
+    emit_cold(P.cold, hitC, fpos, s, sposC, lenC, rl, keyC);
 }
 
 // 16 bytes of batch text at the 16-aligned offset gp, zeros at and behind the vector that holds
@@ -356,18 +411,22 @@ __device__ __forceinline__ uint32_t bits8_at(uint32_t w0, uint32_t w1, uint32_t 
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)lane & 31u) & 0xFFu;
 }
 
-extern "C" __global__ void __launch_bounds__(ST_THREADS, 4)
-kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int64_t fpos_base,
-                const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ tile_chunk,
-                const uint32_t *__restrict__ tile_first, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg)
+// SS = lookup stride of the anchor blocks (SeedTables::stride); STAMPS = diagnostic build that
+// sums wave 0's cycles per phase (KVQ_DBG=16, tools/phase_stamps.py)
+template <int SS, bool STAMPS>
+__global__ void __launch_bounds__(ST_THREADS, 4)
+kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__restrict__ data, int64_t fpos_base,
+                const uint4 *__restrict__ tiles, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
     SeededLds &S = *reinterpret_cast<SeededLds *>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = rfl((uint32_t)tid >> 6);
-    // diagnostic build only (dbg & 16): cycles of wave 0 per phase, summed over tiles
+    HotParams P;
+    P.cold = Pg; P.tab = Pg->tab; P.maxerrors = Pg->maxerrors; P.minoverlap = Pg->minoverlap;
+    P.minreadlength = Pg->minreadlength; P.amin = Pg->amin;
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_t = 0;
-#define STAMP(i) do { if (dbg & 16u) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
+#define STAMP(i) do { if constexpr (STAMPS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
 
     for (int i = tid; i < 4096; i += ST_THREADS) S.bm2[i] = X.bm2[i];
     for (int i = tid; i < KVQ_RL_BINS; i += ST_THREADS) S.hist[i] = 0;
@@ -377,7 +436,7 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
     // the tile's text travels HBM -> registers (one tile ahead) -> LDS
     uint4 pre[ST_ROUNDS];
     if (blockIdx.x < ntiles) {
-        const TileGeo J = tile_geo(blockIdx.x, chunk_off, tile_chunk, tile_first);
+        const TileGeo J = tile_geo(blockIdx.x, tiles);
 #pragma unroll
         for (int r = 0; r < (int)ST_ROUNDS; r++) {
             const uint32_t gp = J.load_lo + (uint32_t)(r * ST_THREADS + tid) * 16u;
@@ -387,8 +446,8 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
     __syncthreads();
 
     for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
-        const TileGeo J = tile_geo(g, chunk_off, tile_chunk, tile_first);
-        if (dbg & 16u) stamp_t = __builtin_amdgcn_s_memtime();
+        const TileGeo J = tile_geo(g, tiles);
+        if constexpr (STAMPS) stamp_t = __builtin_amdgcn_s_memtime();
         // every vector load has to be back here anyway; saying so on all paths keeps the
         // compiler from waiting for the next tile's loads in the middle of this tile
         __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0)
@@ -415,7 +474,7 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
             }
         }
         if (g + gridDim.x < ntiles) {
-            const TileGeo N = tile_geo(g + gridDim.x, chunk_off, tile_chunk, tile_first);
+            const TileGeo N = tile_geo(g + gridDim.x, tiles);
 #pragma unroll
             for (int r = 0; r < (int)ST_ROUNDS; r++) {
                 const uint32_t gp = N.load_lo + (uint32_t)(r * ST_THREADS + tid) * 16u;
@@ -464,9 +523,7 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
 #pragma unroll
                 for (int v = 0; v < (int)(ST_BLK / 16); v++) {
                     // 16 flag bits of this vector, then its (few) set bits
-                    uint32_t m16 = ((fl[4 * v] * 0x00204081u) >> 28) | (((fl[4 * v + 1] * 0x00204081u) >> 28) << 4) |
-                                   (((fl[4 * v + 2] * 0x00204081u) >> 28) << 8) | (((fl[4 * v + 3] * 0x00204081u) >> 28) << 12);
-                    if ((fl[4 * v] | fl[4 * v + 1] | fl[4 * v + 2] | fl[4 * v + 3]) == 0u) m16 = 0;
+                    uint32_t m16 = kvq_flags16(fl[4 * v], fl[4 * v + 1], fl[4 * v + 2], fl[4 * v + 3]);
                     while (m16) {
                         const int bit = __ffs((int)m16) - 1; m16 &= m16 - 1u;
                         if (n < ST_NLCAP) S.nl[n] = (uint16_t)(blk + 16u * v + (uint32_t)bit);
@@ -540,8 +597,8 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                 const uint32_t sread = n0 + 1u, plus = n1 + 1u, sscore = n2 + 1u;
                 if (gl == 0) {
                     const uint32_t c0 = S.buf[rstart], cp = S.buf[plus];
-                    if (c0 != '@') atomicMin(P.err, ((unsigned long long)(tile_fpos + rstart - ST_PRE) << 16) | (0ull << 8) | c0);
-                    else if (cp != '+') atomicMin(P.err, ((unsigned long long)(tile_fpos + plus - ST_PRE) << 16) | (1ull << 8) | cp);
+                    if (c0 != '@') atomicMin(Pg->err, ((unsigned long long)(tile_fpos + rstart - ST_PRE) << 16) | (0ull << 8) | c0);
+                    else if (cp != '+') atomicMin(Pg->err, ((unsigned long long)(tile_fpos + plus - ST_PRE) << 16) | (1ull << 8) | cp);
                 }
                 // quality trim (1055-1068): this lane's slice of the score line -> bitmask of good
                 // bytes (SWAR, a dword at a time) -> longest run by shifts, no per-byte branching
@@ -565,9 +622,7 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                             uint32_t q[4];
 #pragma unroll
                             for (int t = 0; t < 4; t++) q[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
-                            uint32_t g16 = 0;
-#pragma unroll
-                            for (int t = 0; t < 4; t++) g16 |= good4(q[t], addk) << (4 * t);
+                            const uint32_t g16 = kvq_flags16(good_flags(q[0], addk), good_flags(q[1], addk), good_flags(q[2], addk), good_flags(q[3], addk));
                             m |= sh >= 0 ? ((uint64_t)g16 << sh) : ((uint64_t)g16 >> (-sh));
                         }
                         if (n < 64) m &= (1ull << n) - 1ull;
@@ -609,18 +664,40 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                 // v_alignbit, looks it up in the 2-bit bitmap and piles the answers up in registers
                 // only even read positions are looked up (the anchor blocks of a sequence are indexed at
                 // offsets 8j and 8j+1, so an alignment at an odd offset is met through the shifted set)
-                int e0 = 0, e1 = 0; uint32_t pkb = 0;
+                // seed filter: lookups of the read's 8-mers at positions 0, SS, 2 SS, ... in the LDS bitmap
+                // (bit 0: an anchor block of some sequence; bit 1, for the e+1 head and tail blocks only:
+                // anywhere in some sequence); the G lanes of a read share its positions
+                int e0 = 0, e1 = 0;
                 if (mine) {
-                    const int NPe = (rl - (SK - 1) + 1) >> 1;
+                    const int NPe = (rl - SK) / SS + 1;
                     const int per = (NPe + (int)G - 1) >> lg;
                     e0 = (int)gl * per; if (e0 > NPe) e0 = NPe;
                     e1 = e0 + per; if (e1 > NPe) e1 = NPe;
                 }
-                {
-                    // score line of this record starts at nl[m + 2] + 1 (all lanes of the group agree)
+                const int me_ = P.maxerrors;
+                // tail block jj (position rl - 8(jj+1)) of this lane's read
+                auto tail_block = [&](int jj, bool &hit, uint32_t &ppo) {
+                    const int pp = rl - (jj + 1) * SK;
+                    const bool ok = mine && jj <= me_ && pp >= 0 && !((pp % SK) == 0 && pp <= me_ * SK);   // not a tail block that is also a head block
+                    const uint32_t c2 = lds_code8x2(S, roff + (uint32_t)(ok ? pp : 0));
+                    hit = ok && ((S.bm2[c2 >> 5] >> ((c2 & 30u) + 1u)) & 1u);
+                    ppo = (uint32_t)pp;
+                };
+                // lane j of the group takes tail block j; its candidate joins the first round's push
+                bool thit = false; uint32_t tpp = 0;
+                if (__any(mine)) tail_block((int)gl, thit, tpp);
+                // head blocks are lookup positions themselves: lookup numbers 8j / SS, j <= e
+                const uint64_t headpat = (SS == 8 ? ~0ull : SS == 4 ? 0x5555555555555555ull : 0x1111111111111111ull) &
+                                         ((2ull << ((unsigned)(me_ * SK) / SS)) - 1ull);
+                constexpr int NR = SS == 8 ? 6 : 48 / SS;                        // lookups per lane and round
+                uint32_t pkb = 0;
+                if constexpr (SS != 8) {
+                    // the G lanes of a read pack its bases to 2 bits each, 16 per dword, into the record's own
+                    // score line (dead after the trim); the overlapping 8-mers then come out of the packed
+                    // words with one v_alignbit each
                     uint32_t sscore_l = 0; int nw = 0;
                     if (mine) {
-                        sscore_l = (uint32_t)S.nl[jn + 4u * k + 2u] + 1u;
+                        sscore_l = (uint32_t)S.nl[jn + 4u * k + 2u] + 1u;         // score line of this record (all lanes of the group agree)
                         nw = (rl + 15) >> 4;
                     }
                     pkb = (sscore_l + 3u) & ~3u;
@@ -628,95 +705,86 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                         if (i < nw) {
                             const uint32_t src = roff + 16u * (uint32_t)i, w = src & ~3u, sh8 = (src & 3u) * 8u;
                             uint32_t d[5];
-    #pragma unroll
+#pragma unroll
                             for (int t = 0; t < 5; t++) d[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
-                            uint32_t c = 0;
-    #pragma unroll
-                            for (int t = 0; t < 4; t++) {
-                                const uint32_t by = __builtin_amdgcn_alignbit(d[t + 1], d[t], sh8);          // bases 4t..4t+3 of this word
-                                c |= ((((by >> 1) & 0x03030303u) * 0x01041040u) >> 24) << (8 * t);
-                            }
-                            *reinterpret_cast<uint32_t *>(&S.buf[pkb + 4u * (uint32_t)i]) = c;
+                            const uint32_t c01 = code8x2_of(__builtin_amdgcn_alignbit(d[1], d[0], sh8), __builtin_amdgcn_alignbit(d[2], d[1], sh8));
+                            const uint32_t c23 = code8x2_of(__builtin_amdgcn_alignbit(d[3], d[2], sh8), __builtin_amdgcn_alignbit(d[4], d[3], sh8));
+                            *reinterpret_cast<uint32_t *>(&S.buf[pkb + 4u * (uint32_t)i]) = (c01 >> 1) | (c23 << 15);
                         }
                     }
                 }
-                for (int ee = e0; __any(ee < e1); ee += 16) {                  // one round unless a slice exceeds 16 even positions
+                bool first = true;
+                for (int ee = e0; __any(ee < e1); ee += NR, first = false) {    // one round unless a slice exceeds NR lookups
                     const bool act = ee < e1;
-                    uint32_t hbits = 0;                                          // bit j: position 2(ee + j) carries an anchor code
-                    if (__any(act)) {
-                        const uint32_t bit = 4u * (uint32_t)ee;                  // packed stream: 2 bits per base
+                    uint32_t hA = 0, hH = 0;                                     // bit j: lookup ee + j met an anchor code / a code of the ALL index
+                    if constexpr (SS == 8) {
+                        // blocks do not overlap: codes straight from the text, 48 bytes (13 dwords) per round
+                        const uint32_t src = roff + 8u * (uint32_t)(act ? ee : 0), w = src & ~3u, sh8 = (src & 3u) * 8u;
+                        uint32_t D[2 * NR + 1];
+#pragma unroll
+                        for (int t = 0; t < 2 * NR + 1; t++) D[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
+#pragma unroll
+                        for (int j = 0; j < NR; j++) {
+                            const uint32_t c2 = code8x2_of(__builtin_amdgcn_alignbit(D[2 * j + 1], D[2 * j], sh8),
+                                                           __builtin_amdgcn_alignbit(D[2 * j + 2], D[2 * j + 1], sh8));
+                            const uint32_t two = (S.bm2[c2 >> 5] >> (c2 & 30u)) & 3u;
+                            hA |= (two & 1u) << j; hH |= (two >> 1) << j;
+                        }
+                    } else {
+                        const uint32_t bit = act ? 2u * SS * (uint32_t)ee : 0u;  // packed stream: 2 bits per base
                         const uint32_t wi = bit >> 5, bo = bit & 31u;
-                        uint32_t W[4];
+                        uint32_t W[5];
 #pragma unroll
-                        for (int t = 0; t < 4; t++) W[t] = *reinterpret_cast<const uint32_t *>(&S.buf[pkb + 4u * (wi + (uint32_t)t)]);
+                        for (int t = 0; t < 5; t++) W[t] = *reinterpret_cast<const uint32_t *>(&S.buf[pkb + 4u * (wi + (uint32_t)t)]);
                         const uint32_t R0 = __builtin_amdgcn_alignbit(W[1], W[0], bo), R1 = __builtin_amdgcn_alignbit(W[2], W[1], bo),
-                                       R2 = __builtin_amdgcn_alignbit(W[3], W[2], bo);
+                                       R2 = __builtin_amdgcn_alignbit(W[3], W[2], bo), R3 = __builtin_amdgcn_alignbit(W[4], W[3], bo);
 #pragma unroll
-                        for (int j = 0; j < 16; j++) {
-                            const uint32_t win = j < 8 ? __builtin_amdgcn_alignbit(R1, R0, 4 * j) : __builtin_amdgcn_alignbit(R2, R1, 4 * (j - 8));
-                            const uint32_t wv = S.bm2[(win >> 4) & 0xFFFu];
-                            hbits |= ((wv >> ((win << 1) & 31u)) & 1u) << j;
+                        for (int j = 0; j < NR; j++) {
+                            const int b = 2 * SS * j, wj = b >> 5;
+                            const uint32_t lo = wj == 0 ? R0 : wj == 1 ? R1 : R2, hi = wj == 0 ? R1 : wj == 1 ? R2 : R3;
+                            const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(b & 31)) & 0xFFFFu;
+                            const uint32_t two = (S.bm2[win >> 4] >> ((win & 15u) << 1)) & 3u;
+                            hA |= (two & 1u) << j; hH |= (two >> 1) << j;
                         }
-                        const int nv = act ? (e1 - ee < 16 ? e1 - ee : 16) : 0;
-                        hbits &= nv >= 16 ? 0xFFFFu : ((1u << nv) - 1u);
                     }
-                    for (;;) {
-                        const uint64_t mm = __ballot(hbits != 0);
-                        if (!mm) break;
+                    const int nv = act ? (e1 - ee < NR ? e1 - ee : NR) : 0;
+                    const uint32_t vm = (1u << nv) - 1u;                        // nv <= 24
+                    hA &= vm;
+                    hH &= vm & (uint32_t)(ee < 64 ? headpat >> ee : 0ull);
+                    const bool th = first && thit;
+                    // one queue reservation per wave and round, then every lane writes its own candidates
+                    // (read | position << 16, kind << 16; P4a adds the code)
+                    const uint32_t c = (uint32_t)__popc(hA) + (uint32_t)__popc(hH) + (th ? 1u : 0u);
+                    const uint32_t inc = kvq_wave_incl_scan(c);
+                    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                    if (tot) {
                         uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&S.qn, (uint32_t)__popcll(mm));
-                        base = rfl(base);
-                        if (hbits) {
-                            const int j = __ffs((int)hbits) - 1; hbits &= hbits - 1u;
-                            const int pp = 2 * (ee + j);
-                            const uint32_t wq = pkb + 4u * ((uint32_t)pp >> 4);
-                            const uint32_t cd = __builtin_amdgcn_alignbit(*reinterpret_cast<const uint32_t *>(&S.buf[wq + 4u]),
-                                                                          *reinterpret_cast<const uint32_t *>(&S.buf[wq]), ((uint32_t)pp & 15u) * 2u) & 0xFFFFu;
-                            const uint32_t idx = base + (uint32_t)__popcll(mm & kvq_lanemask_lt());
-                            if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)pp << 16), cd);   // beyond the cap: dropped, the stretch is redone in halves
+                        if (lane == 63) base = atomicAdd(&S.qn, tot);
+                        uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - c;
+                        while (hA) {
+                            const int j = __ffs((int)hA) - 1; hA &= hA - 1u;
+                            if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)(SS * (ee + j)) << 16), 0u);   // beyond the cap: dropped, the stretch is redone in halves
+                            idx++;
                         }
+                        while (hH) {
+                            const int j = __ffs((int)hH) - 1; hH &= hH - 1u;
+                            if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)(SS * (ee + j)) << 16), 1u << 16);
+                            idx++;
+                        }
+                        if (th && idx < ST_QCAP) S.q1[idx] = make_uint2(k | (tpp << 16), 1u << 16);
                     }
                 }
-                // the 2(e+1) fixed head / tail blocks of the read against the index of all sequence positions:
-                // the group's first lane takes the head blocks, its last lane the tail blocks; one push round
-                {
-                    uint32_t fx = 0, fcd[14];                                    // bit 2j: head block j hit, bit 2j+1: tail block j hit
-#pragma unroll
-                    for (int j = 0; j < 14; j++) fcd[j] = 0;
-                    if (mine && (gl == 0 || gl == G - 1u)) {
-#pragma unroll
-                        for (int j = 0; j < 7; j++) {
-                            if (j <= P.maxerrors) {
-#pragma unroll
-                                for (int side = 0; side < 2; side++) {
-                                    const int pp = side == 0 ? j * SK : rl - (j + 1) * SK;
-                                    const bool my = side == 0 ? gl == 0 : gl == G - 1u;
-                                    const bool dup = side == 1 && (pp % SK) == 0 && pp <= P.maxerrors * SK;   // a tail block that is also a head block
-                                    if (my && !dup && pp >= 0 && pp + SK <= rl) {
-                                        const uint32_t wq = pkb + 4u * ((uint32_t)pp >> 4);
-                                        const uint32_t cd = __builtin_amdgcn_alignbit(*reinterpret_cast<const uint32_t *>(&S.buf[wq + 4u]),
-                                                                                      *reinterpret_cast<const uint32_t *>(&S.buf[wq]), ((uint32_t)pp & 15u) * 2u) & 0xFFFFu;
-                                        fcd[2 * j + side] = cd | ((uint32_t)pp << 16);
-                                        fx |= ((S.bm2[cd >> 4] >> (((cd & 15u) << 1) + 1u)) & 1u) << (2 * j + side);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    for (;;) {
-                        const uint64_t mm = __ballot(fx != 0);
-                        if (!mm) break;
+                // groups narrower than e+1 lanes: the remaining tail blocks, one push round each
+                for (int t = (int)G; t <= me_; t += (int)G) {
+                    bool hit; uint32_t pp;
+                    tail_block(t + (int)gl, hit, pp);
+                    const uint64_t mm = __ballot(hit);
+                    if (mm) {
                         uint32_t base = 0;
                         if (lane == 0) base = atomicAdd(&S.qn, (uint32_t)__popcll(mm));
                         base = rfl(base);
-                        if (fx) {
-                            const int b2 = __ffs((int)fx) - 1; fx &= fx - 1u;
-                            uint32_t v = 0;
-#pragma unroll
-                            for (int t = 0; t < 14; t++) v = b2 == t ? fcd[t] : v;
-                            const uint32_t idx = base + (uint32_t)__popcll(mm & kvq_lanemask_lt());
-                            if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | (v & 0xFFFF0000u), (v & 0xFFFFu) | (1u << 16));
-                        }
+                        const uint32_t idx = base + (uint32_t)__popcll(mm & kvq_lanemask_lt());
+                        if (hit && idx < ST_QCAP) S.q1[idx] = make_uint2(k | (pp << 16), 1u << 16);
                     }
                 }
                 STAMP(5);
@@ -733,8 +801,9 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                     uint32_t e0 = 0, ne = 0;
                     if (qi < qn) {
                         const uint2 cd = S.q1[qi];
+                        const uint32_t code = lds_code8(S, (S.rinfo[cd.x & 0xFFFFu] & 0xFFFFu) + (cd.x >> 16));
                         const uint32_t *st = (cd.y >> 16) ? X.start_all : X.start_anc;
-                        e0 = st[cd.y & 0xFFFFu]; ne = st[(cd.y & 0xFFFFu) + 1u] - e0;
+                        e0 = st[code]; ne = st[code + 1u] - e0;
                     }
                     const uint32_t inc = kvq_wave_incl_scan(ne);
                     uint32_t base = 0;
@@ -769,7 +838,7 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
                             rec = cd.x & 0xFFFFu; p = (int)(cd.x >> 16); kind = cd.y >> 16;
                             en = (kind ? X.ent_all : X.ent_anc)[it & 0x3FFFFFu];
                         }
-                        verify_item(P, S, active, rec, p, kind, en, tile_fpos);
+                        verify_item(P, S, active, rec, p, kind, en, tile_fpos, SS);
                     }
                 }
                 __syncthreads();                                   // everyone is done with the queues and these reads
@@ -790,13 +859,14 @@ kvq_scan_seeded(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int
         if (nrec == 0) __syncthreads();
     }
 
-    if ((dbg & 16u) && tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&P.ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
+    unsigned long long *const ctr = Pg->ctr;
+    if constexpr (STAMPS) { if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]); }
     // ---- flush per-workgroup counters ----
     for (int i = tid; i < KVQ_RL_BINS; i += ST_THREADS)
-        if (S.hist[i]) atomicAdd(&P.ctr[KVQ_CTR_RL_ + i], (unsigned long long)S.hist[i]);
+        if (S.hist[i]) atomicAdd(&ctr[KVQ_CTR_RL_ + i], (unsigned long long)S.hist[i]);
     if (tid == 0) {
-        if (S.longest_p1) atomicMax(&P.ctr[KVQ_CTR_LONGEST_], (unsigned long long)S.longest_p1);
-        if (S.records) atomicAdd(&P.ctr[KVQ_CTR_RECORDS_], (unsigned long long)S.records);
+        if (S.longest_p1) atomicMax(&ctr[KVQ_CTR_LONGEST_], (unsigned long long)S.longest_p1);
+        if (S.records) atomicAdd(&ctr[KVQ_CTR_RECORDS_], (unsigned long long)S.records);
     }
 }
 
@@ -854,8 +924,10 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     }
     if (nt == 0) return KVQ_OK;
     int rc;
-    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 4096, s->stream))) return rc;
-    const size_t first_at = s->pool.take(((size_t)nchunks + 1) * 4);
+    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 8192, s->stream))) return rc;
+    // first tile of every chunk, then the parameter block: one copy
+    const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
+    const size_t first_at = s->pool.take(first_b + sizeof(KvqParams));
     const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 4);
     uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
     uint64_t acc = 0;
@@ -865,15 +937,21 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         acc += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
     }
     first[nchunks] = (uint32_t)acc;
+    memcpy(s->pool.h + first_at + first_b, &P, sizeof(KvqParams));
     uint32_t *d_first = reinterpret_cast<uint32_t *>(s->pool.d + first_at);
+    const KvqParams *d_params = reinterpret_cast<const KvqParams *>(s->pool.d + first_at + first_b);
     uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
     uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
-    KVQ_HIP(hipMemcpyAsync(d_first, first, ((size_t)nchunks + 1) * 4, hipMemcpyHostToDevice, s->stream));
+    KVQ_HIP(hipMemcpyAsync(d_first, first, first_b + sizeof(KvqParams), hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
 
+    typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t);
+    static const SeededKernel kernels[6] = { kvq_scan_seeded<2, false>, kvq_scan_seeded<4, false>, kvq_scan_seeded<8, false>,
+                                             kvq_scan_seeded<2, true>, kvq_scan_seeded<4, true>, kvq_scan_seeded<8, true> };
     static bool attr_set = false;
     if (!attr_set) {
-        KVQ_HIP(hipFuncSetAttribute((const void *)kvq_scan_seeded, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
+        for (SeededKernel kf : kernels)
+            KVQ_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
         KVQ_HIP(hipFuncSetAttribute((const void *)kvq_scan_planes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kvq_planes_lds_bytes()));
         attr_set = true;
     }
@@ -884,8 +962,9 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
                            d_chunk_off, d_tchunk, d_first, (uint32_t)nt, d_report, dbg);
     } else {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, 512);
-        hipLaunchKernelGGL(kvq_scan_seeded, dim3(grid), dim3(ST_THREADS), sizeof(SeededLds), s->stream, P, ix->dev, d_data, fpos_base,
-                           d_chunk_off, d_tchunk, d_first, (uint32_t)nt, d_report, dbg);
+        const SeededKernel kern = kernels[(ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0) + ((dbg & 16u) ? 3 : 0)];
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), sizeof(SeededLds), s->stream, d_params, ix->dev, d_data, fpos_base,
+                           reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg);
     }
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                        d_first, d_report, s->cur_fail);

@@ -55,8 +55,9 @@ __device__ __forceinline__ uint64_t kvq_lanemask_lt()
 // 0x80 in every byte of x that equals '\n' (exact per byte, no borrow artefacts)
 __device__ __forceinline__ uint32_t kvq_nl_flags(uint32_t x)
 {
-    const uint32_t y = x ^ 0x0A0A0A0Au;
-    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+    // low seven bits differ from 0x0A -> the add carries into bit 7; three instructions on gfx950
+    const uint32_t t = ((x & 0x7F7F7F7Fu) ^ 0x0A0A0A0Au) + 0x7F7F7F7Fu;
+    return ~(t | x) & 0x80808080u;
 }
 
 // 0x80 flags of the bytes of a dword at batch offset p that lie inside [a, b)
@@ -68,6 +69,17 @@ __device__ __forceinline__ uint32_t kvq_range_flags(uint32_t p, uint32_t a, uint
     if (hi <= lo) return 0u;
     const uint64_t m = ((1ull << (8 * hi)) - 1ull) & ~((1ull << (8 * lo)) - 1ull);
     return (uint32_t)m & 0x80808080u;
+}
+
+// 0x80 byte flags of up to four dwords -> one bit per byte (dword 0 in bits 0..3, ...): the
+// byte-wise dot product does the gathering (weights 1, 2, 4, ... on flags of 128 each)
+__device__ __forceinline__ uint32_t kvq_flags16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3)
+{
+    uint32_t a = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
+    a = __builtin_amdgcn_udot4(f1, 0x80402010u, a, false);
+    uint32_t b = __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false);
+    b = __builtin_amdgcn_udot4(f3, 0x80402010u, b, false);
+    return (a >> 7) | (b << 1);
 }
 
 // inclusive prefix sum over the 64 lanes of a wave, all lanes active: six DPP adds
