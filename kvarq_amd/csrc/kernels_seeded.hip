@@ -234,7 +234,7 @@ __device__ __forceinline__ uint32_t good4(uint32_t x, uint32_t addk)
 // the same as 0x80 flags per byte
 __device__ __forceinline__ uint32_t good_flags(uint32_t x, uint32_t addk)
 {
-    return ((x & 0x7F7F7F7Fu) + addk) & ~x & 0x80808080u;
+    return __builtin_amdgcn_bitop3_b32((x & 0x7F7F7F7Fu) + addk, 0x80808080u, x, 0x40);               // t & 0x80.. & ~x
 }
 
 // longest run of ones in the low n (1..64) bits of m, first one if several: length, start
@@ -282,7 +282,7 @@ __device__ __forceinline__ bool seed_live(const SeededLds &S, uint32_t roff, int
 __device__ __forceinline__ int diff_bytes(uint32_t x, uint32_t y)
 {
     const uint32_t v = x ^ y;
-    return __popc((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u);
+    return __popc(__builtin_amdgcn_bitop3_b32((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu, 0x80808080u, v, 0xC8));  // (t | v) & 0x80..
 }
 
 // One work item = one (candidate, index entry) pair = one diagonal of one read
@@ -336,31 +336,37 @@ __device__ __forceinline__ void verify_item(const HotParams &P, const SeededLds 
         const int d = q - p;                             // sequence index = read index + d
         const int a = d < 0 ? -d : 0;
         const int L = (rl < seql - d ? rl : seql - d) - a;
+        // most false candidates die here, on the first 16 bytes of the diagonal (one round trip),
+        // before anything else is worked out for them
+        int mism = 0, j = 0;
+        const uint32_t x = roff + (uint32_t)a; const uint8_t *y = seq + a + d;
+        bool alive = L > 0;
+        if (alive && L >= 16) {
+            uint32_t rw[4], sw[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { __builtin_memcpy(&rw[t], &S.buf[x + 4 * t], 4); __builtin_memcpy(&sw[t], y + 4 * t, 4); }
+#pragma unroll
+            for (int t = 0; t < 4; t++) mism += diff_bytes(rw[t], sw[t]);
+            j = 16;
+            alive = mism <= me;
+        }
         // which reference loops visit this diagonal
         bool canAB = false, canC = false;
         const bool guard = rl > mo && seql > mo;
-        if (d < 0) {
-            const int i = -d;
-            if (i <= rl - seql) { canC = true; lenC = seql; sposC = -i; keyC = (2u << 30) | (uint32_t)i; }              // 1147
-            else if (guard && i <= rl - mo) { canAB = true; lenAB = rl - i; sposAB = -i; keyAB = (0u << 30) | (uint32_t)(rl - mo - i); }   // 1116
-        } else if (d == 0) {
-            canC = true; lenC = rl > seql ? seql : rl; sposC = 0; keyC = 2u << 30;                                         // 1147 / 1163
-        } else {
-            const int i = d;
-            if (guard && i <= seql - mo && i >= seql - rl) { canAB = true; lenAB = seql - i; sposAB = i; keyAB = (1u << 30) | (uint32_t)(seql - mo - i); }   // 1130
-            if (rl <= seql && i <= seql - rl) { canC = true; lenC = rl; sposC = i; keyC = (2u << 30) | (uint32_t)i; }       // 1163
-        }
-        if ((canAB || canC) && L > 0) {
-            int mism = 0, j = 0;
-            const uint32_t x = roff + (uint32_t)a; const uint8_t *y = seq + a + d;
-            if (L >= 16) {                                           // most false candidates die here, after one round trip
-                uint32_t rw[4], sw[4];
-#pragma unroll
-                for (int t = 0; t < 4; t++) { __builtin_memcpy(&rw[t], &S.buf[x + 4 * t], 4); __builtin_memcpy(&sw[t], y + 4 * t, 4); }
-#pragma unroll
-                for (int t = 0; t < 4; t++) mism += diff_bytes(rw[t], sw[t]);
-                j = 16;
+        if (alive) {
+            if (d < 0) {
+                const int i = -d;
+                if (i <= rl - seql) { canC = true; lenC = seql; sposC = -i; keyC = (2u << 30) | (uint32_t)i; }              // 1147
+                else if (guard && i <= rl - mo) { canAB = true; lenAB = rl - i; sposAB = -i; keyAB = (0u << 30) | (uint32_t)(rl - mo - i); }   // 1116
+            } else if (d == 0) {
+                canC = true; lenC = rl > seql ? seql : rl; sposC = 0; keyC = 2u << 30;                                         // 1147 / 1163
+            } else {
+                const int i = d;
+                if (guard && i <= seql - mo && i >= seql - rl) { canAB = true; lenAB = seql - i; sposAB = i; keyAB = (1u << 30) | (uint32_t)(seql - mo - i); }   // 1130
+                if (rl <= seql && i <= seql - rl) { canC = true; lenC = rl; sposC = i; keyC = (2u << 30) | (uint32_t)i; }       // 1163
             }
+        }
+        if (canAB || canC) {
             for (; j + 4 <= L && mism <= me; j += 4) {
                 uint32_t rw, sw;
                 __builtin_memcpy(&rw, &S.buf[x + j], 4); __builtin_memcpy(&sw, y + j, 4);
@@ -583,7 +589,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         // advances 64/G reads and hardly anything runs on the scalar unit
         const int64_t tile_fpos = fpos_base + (int64_t)J.g0;
         uint32_t lg = 0;
-        while (lg < 6u && (2u << lg) * nrec <= ST_THREADS) lg++;
+        while (lg < 6u && (2u << lg) * nrec <= (ST_THREADS >> ((dbg >> 8) & 3u))) lg++;     // (dbg bits 8-9: experiment with narrower groups)
         const uint32_t G = 1u << lg, RP = ST_THREADS >> lg;
         const uint32_t gl = (uint32_t)tid & (G - 1u), gr = (uint32_t)tid >> lg;
         for (uint32_t pass0 = 0; pass0 < nrec; pass0 += RP) {
@@ -625,13 +631,31 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                             const uint32_t g16 = kvq_flags16(good_flags(q[0], addk), good_flags(q[1], addk), good_flags(q[2], addk), good_flags(q[3], addk));
                             m |= sh >= 0 ? ((uint64_t)g16 << sh) : ((uint64_t)g16 >> (-sh));
                         }
-                        if (n < 64) m &= (1ull << n) - 1ull;
+                        const uint64_t nmask = n < 64 ? (1ull << n) - 1ull : ~0ull;
+                        m &= nmask;
                         Seg sub; sub.beg = c0; sub.len = n;
-                        const uint64_t inv = ~m;
-                        sub.pre = inv ? __ffsll((long long)inv) - 1 : 64; if (sub.pre > n) sub.pre = n;
-                        const uint64_t top = ~(m << (64 - n));             // leading ones of the n-bit mask = trailing run
-                        sub.suf = top ? __clzll((long long)top) : 64; if (sub.suf > n) sub.suf = n;
-                        int bl, bs; longest_run64(m, n, bl, bs);
+                        int bl, bs;
+                        uint64_t zz = ~m & nmask;                          // the bad bytes of the slice
+                        if (!__any(__popcll(zz) > 4) && !(dbg & 4u)) {
+                            // the usual case, few bad bytes in any lane's slice: walk them (runs = the gaps between them)
+                            int prev = 0, first = n; bl = 0; bs = 0;
+                            while (__any(zz != 0ull)) {
+                                if (zz) {
+                                    const int p = __ffsll((long long)zz) - 1; zz &= zz - 1ull;
+                                    if (first == n) first = p;
+                                    if (p - prev > bl) { bl = p - prev; bs = prev; }
+                                    prev = p + 1;
+                                }
+                            }
+                            if (n - prev > bl) { bl = n - prev; bs = prev; }
+                            sub.pre = first; sub.suf = n - prev;
+                        } else {
+                            const uint64_t inv = ~m;
+                            sub.pre = inv ? __ffsll((long long)inv) - 1 : 64; if (sub.pre > n) sub.pre = n;
+                            const uint64_t top = ~(m << (64 - n));         // leading ones of the n-bit mask = trailing run
+                            sub.suf = top ? __clzll((long long)top) : 64; if (sub.suf > n) sub.suf = n;
+                            longest_run64(m, n, bl, bs);
+                        }
                         sub.best = bl; sub.bstart = c0 + bs;
                         sg = (c0 == sg.beg) ? sub : seg_merge(sg, sub);
                     }
@@ -961,7 +985,8 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         hipLaunchKernelGGL(kvq_scan_planes, dim3(grid), dim3(512), kvq_planes_lds_bytes(), s->stream, P, ix->dev, d_data, fpos_base,
                            d_chunk_off, d_tchunk, d_first, (uint32_t)nt, d_report, dbg);
     } else {
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, 512);
+        static const uint32_t grid_cap = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 512);   // two workgroups per CU
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, grid_cap);
         const SeededKernel kern = kernels[(ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0) + ((dbg & 16u) ? 3 : 0)];
         hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), sizeof(SeededLds), s->stream, d_params, ix->dev, d_data, fpos_base,
                            reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg);

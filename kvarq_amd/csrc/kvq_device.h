@@ -56,8 +56,9 @@ __device__ __forceinline__ uint64_t kvq_lanemask_lt()
 __device__ __forceinline__ uint32_t kvq_nl_flags(uint32_t x)
 {
     // low seven bits differ from 0x0A -> the add carries into bit 7; three instructions on gfx950
-    const uint32_t t = ((x & 0x7F7F7F7Fu) ^ 0x0A0A0A0Au) + 0x7F7F7F7Fu;
-    return ~(t | x) & 0x80808080u;
+    // (v_bitop3_b32 spelled out: with its constants as literals the compiler falls back to two-input logic)
+    const uint32_t t = __builtin_amdgcn_bitop3_b32(x, 0x0A0A0A0Au, 0x7F7F7F7Fu, 0x6c) + 0x7F7F7F7Fu;   // ((x & 0x7F..) ^ 0x0A..) + 0x7F..
+    return __builtin_amdgcn_bitop3_b32(t, 0x80808080u, x, 0x04);                                      // ~t & 0x80.. & ~x
 }
 
 // 0x80 flags of the bytes of a dword at batch offset p that lie inside [a, b)
