@@ -40,8 +40,10 @@
 #define ST_ROUNDS ((ST_TILE + ST_OV) / 16u / ST_THREADS + 1)    // 16-byte loads per thread
 #define ST_NLCAP 2048
 #define ST_RCAP 512
-#define ST_QCAP 1024            // candidates (read, position) per pass
-#define ST_Q2CAP 2048           // candidate x index entry pairs per pass
+#define ST_QCAP 1024            // candidates (read, position): ST_QW per wave and stretch
+#define ST_Q2CAP 2048           // candidate x index entry pairs: ST_Q2W per wave and stretch
+#define ST_QW (ST_QCAP / ST_WAVES)
+#define ST_Q2W (ST_Q2CAP / ST_WAVES)
 #define ST_BLK 80u              // bytes one thread scans for newlines (LDS conflict-free stride)
 #define ST_BUF (ST_PRE + ST_TILE + ST_OV)
 
@@ -170,7 +172,7 @@ struct SeededLds {
     uint32_t q2[ST_Q2CAP];               // work item: candidate << 22 | index entry
     uint32_t rinfo[ST_RCAP];             // read offset in buf | rl << 16
     uint32_t wtot[ST_WAVES];             // newlines per wave
-    uint32_t n_owned, qn, q2n, longest_p1, records, more, fallback;
+    uint32_t n_owned, longest_p1, records, fallback;
 };
 
 // values that are the same in every lane (LDS reads at uniform addresses, wave
@@ -516,7 +518,6 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
             const uint32_t o = kvq_wave_incl_scan(cnt_owned);
             if (lane == 63 && o) atomicAdd(&S.n_owned, o);
         }
-        if (tid == 0) { S.qn = 0; S.q2n = 0; }
         __syncthreads();
         STAMP(1);
         uint32_t n_all = 0;
@@ -676,12 +677,19 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 }
             }
             STAMP(4);
-            // filter + verify this pass's reads.  Normally one stretch; when the candidate queues
-            // overflow (dense tables, hit-rich reads) the stretch is redone in halves
-            const uint32_t npass = nrec - pass0 < RP ? nrec - pass0 : RP;
-            uint32_t sub = 0, step = RP;
-            for (;;) {
-                const bool mine = have && rl >= P.minreadlength && !(dbg & 2u) && gr >= sub && gr - sub < step;       // 1100
+            // filter + verify, wave by wave: a wave's reads (64/G of them), its candidates and its work
+            // items are its own (queue segments wave * ST_QW / wave * ST_Q2W, counts in scalar
+            // registers), so nothing between here and the end of the tile waits for another wave.
+            // Normally one stretch; when a queue overflows (dense tables, hit-rich reads) the
+            // stretch is redone in halves
+            const uint32_t rpw = 64u >> lg, grw = (uint32_t)lane >> lg;        // reads per wave, this lane's read within the wave
+            const uint32_t wfirst = pass0 + wave * rpw;                        // the wave's first read of this pass
+            const uint32_t npass = wfirst < nrec ? (nrec - wfirst < rpw ? nrec - wfirst : rpw) : 0u;
+            uint2 *const q1 = S.q1 + wave * ST_QW; uint32_t *const q2 = S.q2 + wave * ST_Q2W;
+            uint32_t sub = 0, step = rpw;
+            while (sub < npass) {
+                const bool mine = have && rl >= P.minreadlength && !(dbg & 2u) && grw >= sub && grw - sub < step;       // 1100
+                uint32_t qn = 0;                                                // candidates queued by this wave (uniform)
                 // seed filter.  (1) the G lanes of a read pack its bases to 2 bits each, 16 per dword, into
                 // the record's own score line (dead after the trim); (2) every lane takes a slice of the
                 // 8-mer positions, pulls the 16-bit code of each out of the packed words with one
@@ -782,20 +790,19 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                     const uint32_t inc = kvq_wave_incl_scan(c);
                     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                     if (tot) {
-                        uint32_t base = 0;
-                        if (lane == 63) base = atomicAdd(&S.qn, tot);
-                        uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)base, 63) + inc - c;
+                        uint32_t idx = qn + inc - c;
                         while (hA) {
                             const int j = __ffs((int)hA) - 1; hA &= hA - 1u;
-                            if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)(SS * (ee + j)) << 16), 0u);   // beyond the cap: dropped, the stretch is redone in halves
+                            if (idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)(SS * (ee + j)) << 16), 0u);   // beyond the cap: dropped, the stretch is redone in halves
                             idx++;
                         }
                         while (hH) {
                             const int j = __ffs((int)hH) - 1; hH &= hH - 1u;
-                            if (idx < ST_QCAP) S.q1[idx] = make_uint2(k | ((uint32_t)(SS * (ee + j)) << 16), 1u << 16);
+                            if (idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)(SS * (ee + j)) << 16), 1u << 16);
                             idx++;
                         }
-                        if (th && idx < ST_QCAP) S.q1[idx] = make_uint2(k | (tpp << 16), 1u << 16);
+                        if (th && idx < ST_QW) q1[idx] = make_uint2(k | (tpp << 16), 1u << 16);
+                        qn += tot;
                     }
                 }
                 // groups narrower than e+1 lanes: the remaining tail blocks, one push round each
@@ -804,83 +811,60 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                     tail_block(t + (int)gl, hit, pp);
                     const uint64_t mm = __ballot(hit);
                     if (mm) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&S.qn, (uint32_t)__popcll(mm));
-                        base = rfl(base);
-                        const uint32_t idx = base + (uint32_t)__popcll(mm & kvq_lanemask_lt());
-                        if (hit && idx < ST_QCAP) S.q1[idx] = make_uint2(k | (pp << 16), 1u << 16);
+                        const uint32_t idx = qn + (uint32_t)__popcll(mm & kvq_lanemask_lt());
+                        if (hit && idx < ST_QW) q1[idx] = make_uint2(k | (pp << 16), 1u << 16);
+                        qn += (uint32_t)__popcll(mm);
                     }
                 }
                 STAMP(5);
-                __syncthreads();
-                STAMP(6);
 
                 // ---- P4a: one candidate per lane: index range -> (candidate, entry) work items ----
-                const uint32_t qall = rfl(S.qn);
-                const bool over1 = qall > ST_QCAP;                        // candidates were dropped
-                const uint32_t qn = over1 ? 0u : qall;
-                if (!(dbg & 1u))
-                for (uint32_t q0 = wave * 64u; q0 < qn; q0 += ST_THREADS) {
+                const bool over1 = qn > ST_QW;                            // candidates were dropped
+                const uint32_t qn_ok = (over1 || (dbg & 1u)) ? 0u : qn;
+                uint32_t q2n = 0;                                         // work items queued by this wave (uniform)
+                for (uint32_t q0 = 0; q0 < qn_ok; q0 += 64u) {
                     const uint32_t qi = q0 + lane;
                     uint32_t e0 = 0, ne = 0;
-                    if (qi < qn) {
-                        const uint2 cd = S.q1[qi];
+                    if (qi < qn_ok) {
+                        const uint2 cd = q1[qi];
                         const uint32_t code = lds_code8(S, (S.rinfo[cd.x & 0xFFFFu] & 0xFFFFu) + (cd.x >> 16));
                         const uint32_t *st = (cd.y >> 16) ? X.start_all : X.start_anc;
                         e0 = st[code]; ne = st[code + 1u] - e0;
                     }
                     const uint32_t inc = kvq_wave_incl_scan(ne);
-                    uint32_t base = 0;
-                    if (lane == 63 && inc) base = atomicAdd(&S.q2n, inc);
-                    base = __shfl(base, 63, 64) + inc - ne;
+                    const uint32_t base = q2n + inc - ne;
                     for (uint32_t j = 0; j < ne; j++)
-                        if (base + j < ST_Q2CAP) S.q2[base + j] = (qi << 22) | (e0 + j);
+                        if (base + j < ST_Q2W) q2[base + j] = (qi << 22) | (e0 + j);
+                    q2n += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                 }
-                __syncthreads();
-                const uint32_t q2all = rfl(S.q2n);
-                const bool over = over1 || q2all > ST_Q2CAP;
-                if (over && step > 1u) {
-                    __syncthreads();                                      // everyone has seen the counts
-                    if (tid == 0) { S.qn = 0; S.q2n = 0; }
-                    step >>= 1;
-                    __syncthreads();
-                    continue;
-                }
-                if (over && tid == 0) S.fallback = 1u;                    // one read floods the queues: the batch goes to the exhaustive kernels
+                const bool over = over1 || q2n > ST_Q2W;
+                if (over && step > 1u) { step >>= 1; continue; }
+                if (over && lane == 0) S.fallback = 1u;                   // one read floods the queues: the batch goes to the exhaustive kernels
 
                 // ---- P4b: one work item per lane ----
                 {
-                    const uint32_t q2n = over ? 0u : q2all;
-                    if (!(dbg & 1u))
-                    for (uint32_t i0 = wave * 64u; i0 < q2n; i0 += ST_THREADS) {
+                    const uint32_t q2n_ok = over ? 0u : q2n;
+                    for (uint32_t i0 = 0; i0 < q2n_ok; i0 += 64u) {
                         const uint32_t ii = i0 + lane;
-                        const bool active = ii < q2n;
+                        const bool active = ii < q2n_ok;
                         uint32_t rec = 0, kind = 0; int p = 0; uint64_t en = 0;
                         if (active) {
-                            const uint32_t it = S.q2[ii];
-                            const uint2 cd = S.q1[it >> 22];
+                            const uint32_t it = q2[ii];
+                            const uint2 cd = q1[it >> 22];
                             rec = cd.x & 0xFFFFu; p = (int)(cd.x >> 16); kind = cd.y >> 16;
                             en = (kind ? X.ent_all : X.ent_anc)[it & 0x3FFFFFu];
                         }
                         verify_item(P, S, active, rec, p, kind, en, tile_fpos, SS);
                     }
                 }
-                __syncthreads();                                   // everyone is done with the queues and these reads
                 sub += step;
-                if (sub >= npass) break;
-                if (tid == 0) { S.qn = 0; S.q2n = 0; }
-                __syncthreads();
             }
-            if (pass0 + RP < nrec) {                               // another pass follows: empty the queues for it
-                if (tid == 0) { S.qn = 0; S.q2n = 0; }
-                __syncthreads();
-            }
-            STAMP(7);
+            STAMP(6);
         }
-        // (the barrier that ended the last pass also protects buf against the next tile's fill;
-        // the queues are emptied again in P1 of the next tile)
+        // everyone is done with the tile's text before the next tile's fill
+        __syncthreads();
+        STAMP(7);
         if (tid == 0 && S.fallback) atomicOr(&tile_report[g], TR_FLAG_FALLBACK);
-        if (nrec == 0) __syncthreads();
     }
 
     unsigned long long *const ctr = Pg->ctr;
