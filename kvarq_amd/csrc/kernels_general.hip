@@ -297,8 +297,46 @@ __device__ __forceinline__ int base_class(uint8_t c)
     return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : 5;
 }
 
-// hits [*range_begin, min(*range_end, cap)) of the arena, one wave per hit: the lanes share
-// out the hit's bases (coverage / mutation counters, hit bytes), lane 0 does the per-hit part.
+// hits [*range_begin, min(*range_end, cap)) of the arena, first pass, one LANE per hit: per-hit
+// counters, coverage marks, and the place of the hit's bytes in the blob (prefix sum over the
+// wave's 64 hits, one reservation per wave -- a reservation per hit would queue up on blob_n).
+extern "C" __global__ void __launch_bounds__(256)
+kvq_fold_offsets(KvqParams P, const unsigned int *__restrict__ range_begin, const unsigned int *__restrict__ range_end)
+{
+    const uint32_t h0 = *range_begin;
+    uint32_t h1 = *range_end; if (h1 > P.arena_cap) h1 = P.arena_cap;
+    const int lane = kvq_lane();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    if (wave == 0 && lane == 0 && h1 > h0) atomicAdd(&P.ctr[KVQ_CTR_HITS_], (unsigned long long)(h1 - h0));
+    for (uint32_t hb = h0 + wave * 64u; hb < h1; hb += nwaves * 64u) {
+        const uint32_t h = hb + (uint32_t)lane;
+        const bool valid = h < h1;
+        int s = 0, len = 0, seq_pos = 0;
+        if (valid) { const KvqHit hit = P.arena[h]; s = hit.seq_nr; len = hit.length; seq_pos = hit.seq_pos; }
+        const uint32_t ulen = len > 0 ? (uint32_t)len : 0u;
+        if (valid) {
+            const int start = seq_pos > 0 ? seq_pos : 0;                              // analyse.py:70
+            const int64_t at = (int64_t)P.tab_off[s] + start;
+            atomicAdd(&P.ctr[P.off_nseqhits + s], 1ull);                              // 435
+            atomicAdd(&P.ctr[P.off_nseqbasehits + s], (unsigned long long)len);       // 434
+            if (len > 0) {
+                // coverage[start .. start + len) += 1 (analyse.py:76) as two marks; kvq_cov_apply sums them up
+                atomicAdd(&P.covdiff[at + s], 1ull);
+                atomicAdd(&P.covdiff[at + s + len], ~0ull);
+            }
+        }
+        const uint32_t incl = kvq_wave_incl_scan(ulen);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        unsigned long long base = 0;
+        if (lane == 0 && tot) base = atomicAdd(P.blob_n, (unsigned long long)tot);
+        base = ((unsigned long long)__shfl((unsigned int)(base >> 32), 0, 64) << 32) | __shfl((unsigned int)base, 0, 64);
+        const unsigned long long boff = base + incl - ulen;
+        if (valid) P.arena[h].blob_off = boff + ulen <= P.blob_cap ? (uint32_t)boff : 0xFFFFFFFFu;
+    }
+}
+
+// second pass, one WAVE per hit: the lanes share out the hit's bases (hit bytes into the blob at
+// the offset the first pass chose, mutation counters)
 extern "C" __global__ void __launch_bounds__(256)
 kvq_fold_hits(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base,
               const unsigned int *__restrict__ range_begin, const unsigned int *__restrict__ range_end)
@@ -314,21 +352,37 @@ kvq_fold_hits(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base,
         const uint8_t *src = data + (hit.fpos - fpos_base) + (hit.seq_pos < 0 ? -hit.seq_pos : 0);
         const uint8_t *seq = P.tab + P.tab_off[s] + start;
         const int64_t at = (int64_t)P.tab_off[s] + start;
-        unsigned long long boff = 0;
-        if (lane == 0) {
-            atomicAdd(&P.ctr[P.off_nseqhits + s], 1ull);                              // 435
-            atomicAdd(&P.ctr[P.off_nseqbasehits + s], (unsigned long long)len);       // 434
-            atomicAdd(&P.ctr[KVQ_CTR_HITS_], 1ull);
-            boff = atomicAdd(P.blob_n, (unsigned long long)len);
-        }
-        boff = ((unsigned long long)__shfl((unsigned int)(boff >> 32), 0, 64) << 32) | __shfl((unsigned int)boff, 0, 64);
-        const bool fits = boff + (unsigned long long)len <= P.blob_cap;
+        const bool fits = hit.blob_off != 0xFFFFFFFFu;
         for (int j = lane; j < len; j += 64) {
             const uint8_t c = src[j];
-            atomicAdd(&P.ctr[P.off_cov + at + j], 1ull);                              // analyse.py:76
             if (c != seq[j]) atomicAdd(&P.ctr[P.off_mut + (at + j) * 6 + base_class(c)], 1ull);   // analyse.py:77-78
-            if (fits) P.blob[boff + j] = c;                                           // 437
+            if (fits) P.blob[(size_t)hit.blob_off + j] = c;                           // 437
         }
-        if (lane == 0) P.arena[h].blob_off = fits ? (uint32_t)boff : 0xFFFFFFFFu;
+    }
+}
+
+// one wave per sequence: running sum of the coverage marks kvq_fold_hits left, added to the
+// coverage counters; the marks are cleared on the way
+extern "C" __global__ void __launch_bounds__(256)
+kvq_cov_apply(KvqParams P)
+{
+    const int s = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (s >= P.nseq) return;
+    const int lane = kvq_lane();
+    const int64_t t0 = P.tab_off[s], len = (int64_t)P.tab_off[s + 1] - t0;
+    unsigned long long *d = P.covdiff + t0 + s;
+    unsigned long long carry = 0;
+    for (int64_t i0 = 0; i0 <= len; i0 += 64) {
+        const int64_t i = i0 + lane;
+        unsigned long long v = 0;
+        if (i <= len) { v = d[i]; if (v) d[i] = 0; }
+        // inclusive scan of the marks over the wave (64-bit, modulo 2^64: -1 marks are ~0)
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long u = ((unsigned long long)__shfl_up((unsigned int)(v >> 32), o, 64) << 32) | __shfl_up((unsigned int)v, o, 64);
+            if (lane >= o) v += u;
+        }
+        v += carry;
+        if (i < len && v) atomicAdd(&P.ctr[P.off_cov + t0 + i], v);
+        carry = ((unsigned long long)__shfl((unsigned int)(v >> 32), 63, 64) << 32) | __shfl((unsigned int)v, 63, 64);
     }
 }

@@ -37,6 +37,7 @@ struct KvqParams {
     const uint8_t *tab;           // concatenated sequence bytes
     const int32_t *tab_off;       // nseq + 1 prefix sums
     unsigned long long *ctr;      // counters (int64 slots)
+    unsigned long long *covdiff;  // coverage as +1 / -1 marks per hit (slot tab_off[s] + s + position), summed up into ctr by kvq_cov_apply
     int64_t off_nseqhits, off_nseqbasehits, off_cov, off_mut;
     KvqHit *arena; uint32_t arena_cap;
     unsigned int *arena_n;        // hits emitted so far (keeps counting past cap)

@@ -78,6 +78,7 @@ struct kvq_scan {
     // per-batch scratch
     DevBuf d_chunk_off, d_seg_base, d_seg_cnt, d_chunk_nrec, d_rec_base, d_nl4, d_rec_start, d_read_off, d_read_len;
     // hit arena
+    DevBuf d_covdiff;                  // coverage marks (KvqParams::covdiff)
     DevBuf d_arena, d_blob, d_small;   // d_small: arena_n, batch range words, blob_n, err
     uint32_t arena_cap = 0; uint64_t blob_cap = 0;
     unsigned int *d_arena_n = nullptr, *d_range = nullptr, *d_fail = nullptr, *cur_fail = nullptr;

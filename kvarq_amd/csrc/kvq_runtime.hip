@@ -213,6 +213,7 @@ static int reset_device_state(kvq_scan *s)
     KVQ_HIP(hipMemsetAsync(s->d_small.p, 0, SMALL_BYTES, s->stream));
     KVQ_HIP(hipMemsetAsync(s->d_err, 0xFF, 16, s->stream));       // err and the staged err
     KVQ_HIP(hipMemsetAsync(s->d_ctr, 0, (size_t)s->t->ctr_len * 8, s->stream));
+    KVQ_HIP(hipMemsetAsync(s->d_covdiff.p, 0, ((size_t)s->t->bases + (size_t)s->t->nseq + 1) * 8, s->stream));
     return KVQ_OK;
 }
 
@@ -245,6 +246,7 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
         s->own_ctr = true;
     }
     if (s->d_small.ensure(SMALL_BYTES) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
+    if (s->d_covdiff.ensure(((size_t)t->bases + (size_t)t->nseq + 1) * 8) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     s->d_arena_n = (unsigned int *)s->d_small.p;
     s->d_blob_n = (unsigned long long *)((char *)s->d_small.p + 8);
     s->d_err = (unsigned long long *)((char *)s->d_small.p + 16);
@@ -280,7 +282,7 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     if (s->own_ctr && s->d_ctr) (void)hipFree(s->d_ctr);
     if (s->pin) (void)hipHostFree(s->pin);
     if (s->pin_small) (void)hipHostFree(s->pin_small);
-    DevBuf *bufs[] = { &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
+    DevBuf *bufs[] = { &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_covdiff, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
                        &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
     for (DevBuf *b : bufs) b->release();
     s->pool.release();
@@ -312,7 +314,7 @@ static KvqParams make_params(const kvq_scan *s)
     P.maxerrors = t->cfg.maxerrors; P.minoverlap = t->cfg.minoverlap; P.minreadlength = t->cfg.minreadlength;
     P.amin = (int32_t)t->cfg.Amin; P.nseq = t->nseq;
     P.tab = t->d_tab.as<uint8_t>(); P.tab_off = t->d_off.as<int32_t>();
-    P.ctr = s->d_ctr;
+    P.ctr = s->d_ctr; P.covdiff = s->d_covdiff.as<unsigned long long>();
     P.off_nseqhits = t->off_nseqhits; P.off_nseqbasehits = t->off_nseqbasehits; P.off_cov = t->off_cov; P.off_mut = t->off_mut;
     P.arena = s->d_arena.as<KvqHit>(); P.arena_cap = s->arena_cap; P.arena_n = s->d_arena_n;
     P.blob = s->d_blob.as<uint8_t>(); P.blob_cap = s->blob_cap; P.blob_n = s->d_blob_n;
@@ -441,6 +443,8 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
                            (const unsigned int *)(s->d_fail + batch_no), s->d_arena_n, (const unsigned int *)(s->d_range + batch_no));
     // hits of this batch = arena[range[batch_no], range[batch_no + 1])
     KVQ_HIP(hipMemcpyAsync(s->d_range + batch_no + 1, s->d_arena_n, 4, hipMemcpyDeviceToDevice, s->stream));
+    hipLaunchKernelGGL(kvq_fold_offsets, dim3(64), dim3(256), 0, s->stream, P,
+                       (const unsigned int *)(s->d_range + batch_no), (const unsigned int *)(s->d_range + batch_no + 1));
     hipLaunchKernelGGL(kvq_fold_hits, dim3(512), dim3(256), 0, s->stream, P, d_data, fpos_base,
                        (const unsigned int *)(s->d_range + batch_no), (const unsigned int *)(s->d_range + batch_no + 1));
     KVQ_HIP(hipEventRecord(s->ev_all.back().second, s->stream));
@@ -540,6 +544,9 @@ static int finish_once(kvq_scan *s)
         rc = ensure_arena(s, want_hits, want_blob); if (rc) return rc;
         return KVQ_NEED_RESCAN;
     }
+    // coverage marks of all batches -> coverage counters
+    if (s->t->nseq > 0)
+        hipLaunchKernelGGL(kvq_cov_apply, dim3((uint32_t)((s->t->nseq + 3) / 4)), dim3(256), 0, s->stream, make_params(s));
     // results: put into canonical order and into their final arrays on the device
     // (kernels_results.hip), then one pinned host buffer takes the arrays and the counters
     const KvqResultLayout L = kvq_result_layout(n_hits, blob_n);
