@@ -171,8 +171,8 @@ struct SeededLds {
     uint2    q1[ST_QCAP];                // candidate: x = rec | pos << 16, y = code | kind << 16
     uint32_t q2[ST_Q2CAP];               // work item: candidate << 22 | index entry
     uint32_t rinfo[ST_RCAP];             // read offset in buf | rl << 16
-    uint32_t wtot[ST_WAVES];             // newlines per wave
-    uint32_t n_owned, longest_p1, records, fallback;
+    uint32_t wtot[ST_WAVES], wown[ST_WAVES];   // newlines per wave: all, and those the tile owns
+    uint32_t longest_p1, records, fallback;
 };
 
 // values that are the same in every lane (LDS reads at uniform addresses, wave
@@ -438,18 +438,21 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
 
     for (int i = tid; i < 4096; i += ST_THREADS) S.bm2[i] = X.bm2[i];
     for (int i = tid; i < KVQ_RL_BINS; i += ST_THREADS) S.hist[i] = 0;
-    if (tid == 0) { S.longest_p1 = 0; S.records = 0; }
+    if (tid == 0) { S.longest_p1 = 0; S.records = 0; S.fallback = 0; }
     if (tid < (int)(ST_PRE / 4)) reinterpret_cast<uint32_t *>(S.buf)[tid] = 0;      // the block in front of the tile never holds text
 
-    // the tile's text travels HBM -> registers (one tile ahead) -> LDS
+    // the tile's text travels HBM -> registers (one tile ahead) -> LDS.  Every thread fetches the
+    // ST_BLK contiguous bytes it will scan for newlines (five 16-byte vectors; thread 0 stands for
+    // the empty block in front of the tile), so the scan works on registers and needs no barrier
+    // behind the LDS fill
+    static_assert(ST_ROUNDS * 16u == ST_BLK, "one scan block per thread");
     uint4 pre[ST_ROUNDS];
+    const uint32_t blk = (uint32_t)tid * ST_BLK;                           // the block's place in buf
+    const uint32_t toff = blk - ST_PRE;                                    // ... and in the tile's text (tid >= 1)
     if (blockIdx.x < ntiles) {
         const TileGeo J = tile_geo(blockIdx.x, tiles);
 #pragma unroll
-        for (int r = 0; r < (int)ST_ROUNDS; r++) {
-            const uint32_t gp = J.load_lo + (uint32_t)(r * ST_THREADS + tid) * 16u;
-            pre[r] = text_load16(data, gp, J.load_hi);
-        }
+        for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? J.load_lo + toff + 16u * r : ~15u, J.load_hi);
     }
     __syncthreads();
 
@@ -460,15 +463,20 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         // compiler from waiting for the next tile's loads in the middle of this tile
         __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0)
 
-        // ---- P0: registers -> LDS (coalesced order); the next tile's loads go out ----
+        // ---- P0 + P1a: registers -> LDS and newline flags of the thread's block; the next tile's loads go out ----
         // bytes in front of the chunk start and behind the loaded text are zeroed here (at most
-        // two vectors per tile), so that the scan below needs no masks
+        // two vectors per tile), so that nothing below needs masks.  (80-byte stride: the five
+        // ds_write_b128 of a wave are bank-conflict free; ownership ends on a block boundary, so a
+        // block is owned entirely or not at all)
+        const uint32_t own_end_l = J.own_end - J.g0 + ST_PRE;              // ownership ends here
+        const uint32_t end_l = J.load_hi - J.g0 + ST_PRE;                  // end of the loaded text
+        uint32_t fl[ST_BLK / 4]; uint32_t cnt = 0;
 #pragma unroll
         for (int r = 0; r < (int)ST_ROUNDS; r++) {
-            const uint32_t off = (uint32_t)(r * ST_THREADS + tid) * 16u;          // relative to g0
+            const uint32_t off = toff + 16u * r;                                  // relative to g0
             const uint32_t gp = J.g0 + off;
-            if (gp < J.load_hi) {
-                uint4 v = pre[r];
+            uint4 v = pre[r];
+            if (tid && gp < J.load_hi) {
                 if (gp < J.own_begin || gp + 16u > J.load_hi) {
                     uint32_t x[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
@@ -479,52 +487,31 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                     v = make_uint4(x[0], x[1], x[2], x[3]);
                 }
                 *reinterpret_cast<uint4 *>(&S.buf[ST_PRE + off]) = v;
-            }
+            } else v = make_uint4(0, 0, 0, 0);
+            fl[4 * r + 0] = kvq_nl_flags(v.x); fl[4 * r + 1] = kvq_nl_flags(v.y);
+            fl[4 * r + 2] = kvq_nl_flags(v.z); fl[4 * r + 3] = kvq_nl_flags(v.w);
         }
         if (g + gridDim.x < ntiles) {
             const TileGeo N = tile_geo(g + gridDim.x, tiles);
 #pragma unroll
-            for (int r = 0; r < (int)ST_ROUNDS; r++) {
-                const uint32_t gp = N.load_lo + (uint32_t)(r * ST_THREADS + tid) * 16u;
-                pre[r] = text_load16(data, gp, N.load_hi);
-            }
-        }
-        if (tid == 0) { S.n_owned = 0; S.fallback = 0; }
-        __syncthreads();
-        STAMP(0);
-
-        // ---- P1: every thread scans ST_BLK contiguous bytes of the tile for '\n' ----
-        // (80-byte stride: the five ds_read_b128 of a wave are bank-conflict free; ownership
-        // ends on a block boundary, so a block is owned entirely or not at all)
-        const uint32_t own_end_l = J.own_end - J.g0 + ST_PRE;              // ownership ends here
-        const uint32_t end_l = J.load_hi - J.g0 + ST_PRE;                  // end of the loaded text
-        uint32_t fl[ST_BLK / 4]; uint32_t cnt = 0;
-        const uint32_t blk = (uint32_t)tid * ST_BLK;
-#pragma unroll
-        for (int v = 0; v < (int)(ST_BLK / 16); v++) {
-            if (blk + 16u * v < end_l) {                                    // vectors behind the text hold stale bytes
-                const uint4 w = *reinterpret_cast<const uint4 *>(&S.buf[blk + 16u * v]);
-                fl[4 * v + 0] = kvq_nl_flags(w.x); fl[4 * v + 1] = kvq_nl_flags(w.y);
-                fl[4 * v + 2] = kvq_nl_flags(w.z); fl[4 * v + 3] = kvq_nl_flags(w.w);
-            } else { fl[4 * v + 0] = fl[4 * v + 1] = fl[4 * v + 2] = fl[4 * v + 3] = 0; }
+            for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? N.load_lo + toff + 16u * r : ~15u, N.load_hi);
         }
 #pragma unroll
         for (int d = 0; d < (int)(ST_BLK / 4); d++) cnt += __popc(fl[d]);
         const uint32_t cnt_owned = blk < own_end_l ? cnt : 0u;            // own_end_l is a block boundary or the end of the text
         const uint32_t incl = kvq_wave_incl_scan(cnt);
-        if (lane == 63) S.wtot[wave] = incl;
         {
-            // owned newlines: one LDS atomic per wave
             const uint32_t o = kvq_wave_incl_scan(cnt_owned);
-            if (lane == 63 && o) atomicAdd(&S.n_owned, o);
+            if (lane == 63) { S.wtot[wave] = incl; S.wown[wave] = o; }
         }
+        STAMP(0);
         __syncthreads();
         STAMP(1);
-        uint32_t n_all = 0;
+        uint32_t n_all = 0, n_own_all = 0;
         {
             uint32_t mine = 0;
 #pragma unroll
-            for (int w = 0; w < ST_WAVES; w++) { const uint32_t t = S.wtot[w]; if (w == (int)wave) mine = n_all; n_all += t; }
+            for (int w = 0; w < ST_WAVES; w++) { const uint32_t t = S.wtot[w]; if (w == (int)wave) mine = n_all; n_all += t; n_own_all += S.wown[w]; }
             uint32_t n = mine + incl - cnt;
             if (cnt) {
 #pragma unroll
@@ -547,7 +534,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         uint32_t nrec = 0, jn = TR_NONE;
         {
             const uint32_t n_nl = n_all < ST_NLCAP ? n_all : ST_NLCAP;
-            const uint32_t n_owned = rfl(S.n_owned);
+            const uint32_t n_owned = rfl(n_own_all);
             uint32_t fallback = n_all > ST_NLCAP ? 1u : 0u;
             // a record belongs to the tile that owns the '\n' in front of it (the chunk's
             // first record to tile 0), also when its first byte is the next tile's first
@@ -864,7 +851,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         // everyone is done with the tile's text before the next tile's fill
         __syncthreads();
         STAMP(7);
-        if (tid == 0 && S.fallback) atomicOr(&tile_report[g], TR_FLAG_FALLBACK);
+        if (tid == 0 && S.fallback) { atomicOr(&tile_report[g], TR_FLAG_FALLBACK); S.fallback = 0; }
     }
 
     unsigned long long *const ctr = Pg->ctr;
