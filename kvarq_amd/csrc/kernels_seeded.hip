@@ -52,7 +52,8 @@
 #define TR_FLAG_FALLBACK 0x2000000u
 
 struct SeedTables {
-    const uint32_t *bm2;                      // 2 bits per 8-mer code: bit 0 = an anchor block, bit 1 = anywhere in a sequence
+    const uint32_t *bm2;                      // 2 bits per 8-mer code: bit 0 = an anchor block, bit 1 = anywhere in a sequence (planes kernel)
+    const uint32_t *bm1;                      // the same as two bitmaps of 8 KiB, one bit per code: anchor blocks, then anywhere
     const uint32_t *start_anc, *start_all;    // CSR starts, 65537 entries
     // entry: position in sequence (12) | sequence number (20) | table offset of the sequence (20) | its length (12)
     const uint64_t *ent_anc, *ent_all;
@@ -69,7 +70,7 @@ uint32_t kvq_planes_tile_bytes();
 struct SeedIndex {
     int variant = 0;          // 0 = kvq_scan_seeded, 1 = kvq_scan_planes (KVQ_KERNEL=planes)
     int stride = 2;           // anchor blocks sit at sequence offsets 8j + 0 .. 8j + stride - 1
-    DevBuf d_bm2, d_start_anc, d_start_all, d_ent_anc, d_ent_all;
+    DevBuf d_bm2, d_bm1, d_start_anc, d_start_all, d_ent_anc, d_ent_all;
     SeedTables dev;
 };
 
@@ -129,22 +130,28 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     SeedIndex *ix = new SeedIndex();
     ix->variant = variant; ix->stride = stride;
     std::vector<uint32_t> bm2(4096, 0);
+    std::vector<uint8_t> bm1(16384, 0);
     auto upload = [&](std::vector<std::pair<uint32_t, uint64_t>> &v, int bit, DevBuf &st, DevBuf &en) -> bool {
         std::sort(v.begin(), v.end());
         std::vector<uint32_t> start(65537, 0); std::vector<uint64_t> ent(v.size() + 1, 0);
-        for (size_t i = 0; i < v.size(); i++) { bm2[v[i].first >> 4] |= 1u << (2 * (v[i].first & 15) + bit); start[v[i].first + 1]++; ent[i] = v[i].second; }
+        for (size_t i = 0; i < v.size(); i++) {
+            bm2[v[i].first >> 4] |= 1u << (2 * (v[i].first & 15) + bit);
+            bm1[(size_t)bit * 8192 + (v[i].first >> 3)] |= (uint8_t)(1u << (v[i].first & 7));
+            start[v[i].first + 1]++; ent[i] = v[i].second;
+        }
         for (int c = 0; c < 65536; c++) start[c + 1] += start[c];
         return st.ensure(65537 * 4) == KVQ_OK && en.ensure(ent.size() * 8) == KVQ_OK &&
                hipMemcpy(st.p, start.data(), 65537 * 4, hipMemcpyHostToDevice) == hipSuccess &&
                hipMemcpy(en.p, ent.data(), ent.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
     };
     if (!upload(anc, 0, ix->d_start_anc, ix->d_ent_anc) || !upload(all, 1, ix->d_start_all, ix->d_ent_all) ||
-        ix->d_bm2.ensure(16384) != KVQ_OK || hipMemcpy(ix->d_bm2.p, bm2.data(), 16384, hipMemcpyHostToDevice) != hipSuccess) {
+        ix->d_bm2.ensure(16384) != KVQ_OK || hipMemcpy(ix->d_bm2.p, bm2.data(), 16384, hipMemcpyHostToDevice) != hipSuccess ||
+        ix->d_bm1.ensure(16384) != KVQ_OK || hipMemcpy(ix->d_bm1.p, bm1.data(), 16384, hipMemcpyHostToDevice) != hipSuccess) {
         if (!kvq_error_code()) kvq_set_error(KVQ_ERR_DEVICE, "uploading the seed index failed");
         kvq_seed_index_destroy(ix);
         return nullptr;
     }
-    ix->dev.bm2 = ix->d_bm2.as<uint32_t>();
+    ix->dev.bm2 = ix->d_bm2.as<uint32_t>(); ix->dev.bm1 = ix->d_bm1.as<uint32_t>();
     ix->dev.start_anc = ix->d_start_anc.as<uint32_t>(); ix->dev.start_all = ix->d_start_all.as<uint32_t>();
     ix->dev.ent_anc = ix->d_ent_anc.as<uint64_t>(); ix->dev.ent_all = ix->d_ent_all.as<uint64_t>();
     ix->dev.stride = stride;
@@ -154,7 +161,7 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
 void kvq_seed_index_destroy(SeedIndex *ix)
 {
     if (!ix) return;
-    DevBuf *b[] = { &ix->d_bm2, &ix->d_start_anc, &ix->d_start_all, &ix->d_ent_anc, &ix->d_ent_all };
+    DevBuf *b[] = { &ix->d_bm2, &ix->d_bm1, &ix->d_start_anc, &ix->d_start_all, &ix->d_ent_anc, &ix->d_ent_all };
     for (DevBuf *x : b) x->release();
     delete ix;
 }
@@ -166,7 +173,7 @@ void kvq_seed_index_destroy(SeedIndex *ix)
 struct SeededLds {
     uint8_t  buf[ST_BUF];                // buf[ST_PRE] = first byte the tile owns
     uint16_t nl[ST_NLCAP];               // offsets into buf of every '\n', ascending
-    uint32_t bm2[4096];                  // 2 bits per 8-mer code (anchor / anywhere)
+    uint8_t  bmA[8192], bmL[8192];       // one bit per 8-mer code: an anchor block of some sequence / anywhere in some sequence
     uint32_t hist[KVQ_RL_BINS];
     uint2    q1[ST_QCAP];                // candidate: x = rec | pos << 16, y = code | kind << 16
     uint32_t q2[ST_Q2CAP];               // work item: candidate << 22 | index entry
@@ -436,7 +443,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_t = 0;
 #define STAMP(i) do { if constexpr (STAMPS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
 
-    for (int i = tid; i < 4096; i += ST_THREADS) S.bm2[i] = X.bm2[i];
+    for (int i = tid; i < 4096; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = X.bm1[i];     // bmA and bmL are adjacent
     for (int i = tid; i < KVQ_RL_BINS; i += ST_THREADS) S.hist[i] = 0;
     if (tid == 0) { S.longest_p1 = 0; S.records = 0; S.fallback = 0; }
     if (tid < (int)(ST_PRE / 4)) reinterpret_cast<uint32_t *>(S.buf)[tid] = 0;      // the block in front of the tile never holds text
@@ -677,15 +684,9 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
             while (sub < npass) {
                 const bool mine = have && rl >= P.minreadlength && !(dbg & 2u) && grw >= sub && grw - sub < step;       // 1100
                 uint32_t qn = 0;                                                // candidates queued by this wave (uniform)
-                // seed filter.  (1) the G lanes of a read pack its bases to 2 bits each, 16 per dword, into
-                // the record's own score line (dead after the trim); (2) every lane takes a slice of the
-                // 8-mer positions, pulls the 16-bit code of each out of the packed words with one
-                // v_alignbit, looks it up in the 2-bit bitmap and piles the answers up in registers
-                // only even read positions are looked up (the anchor blocks of a sequence are indexed at
-                // offsets 8j and 8j+1, so an alignment at an odd offset is met through the shifted set)
-                // seed filter: lookups of the read's 8-mers at positions 0, SS, 2 SS, ... in the LDS bitmap
-                // (bit 0: an anchor block of some sequence; bit 1, for the e+1 head and tail blocks only:
-                // anywhere in some sequence); the G lanes of a read share its positions
+                // seed filter: the read's 8-mers at positions 0, SS, 2 SS, ... are looked up in the LDS
+                // bitmap of anchor blocks (the G lanes of a read share the positions); its e+1 head
+                // blocks (positions 8j) and tail blocks (rl - 8(j+1)) in the bitmap of all sequence 8-mers
                 int e0 = 0, e1 = 0;
                 if (mine) {
                     const int NPe = (rl - SK) / SS + 1;
@@ -694,20 +695,20 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                     e1 = e0 + per; if (e1 > NPe) e1 = NPe;
                 }
                 const int me_ = P.maxerrors;
-                // tail block jj (position rl - 8(jj+1)) of this lane's read
-                auto tail_block = [&](int jj, bool &hit, uint32_t &ppo) {
-                    const int pp = rl - (jj + 1) * SK;
-                    const bool ok = mine && jj <= me_ && pp >= 0 && !((pp % SK) == 0 && pp <= me_ * SK);   // not a tail block that is also a head block
-                    const uint32_t c2 = lds_code8x2(S, roff + (uint32_t)(ok ? pp : 0));
-                    hit = ok && ((S.bm2[c2 >> 5] >> ((c2 & 30u) + 1u)) & 1u);
-                    ppo = (uint32_t)pp;
+                // is the 8-mer at read position pp anywhere in a sequence?
+                auto fixed_block = [&](int pp, bool ok) -> bool {
+                    const uint32_t code = lds_code8x2(S, roff + (uint32_t)(ok ? pp : 0)) >> 1;
+                    return ok && ((S.bmL[code >> 3] >> (code & 7u)) & 1u);
                 };
-                // lane j of the group takes tail block j; its candidate joins the first round's push
-                bool thit = false; uint32_t tpp = 0;
-                if (__any(mine)) tail_block((int)gl, thit, tpp);
-                // head blocks are lookup positions themselves: lookup numbers 8j / SS, j <= e
-                const uint64_t headpat = (SS == 8 ? ~0ull : SS == 4 ? 0x5555555555555555ull : 0x1111111111111111ull) &
-                                         ((2ull << ((unsigned)(me_ * SK) / SS)) - 1ull);
+                // lane j of the group takes head block j and tail block j (a tail block that is also a
+                // head block counts as head block only); their candidates join the first round's push
+                auto head_ok = [&](int jj) { return mine && jj <= me_ && (jj + 1) * SK <= rl; };
+                auto tail_ok = [&](int jj) { const int pp = rl - (jj + 1) * SK; return mine && jj <= me_ && pp >= 0 && !((pp % SK) == 0 && pp <= me_ * SK); };
+                bool hhit = false, thit = false;
+                if (__any(mine)) {
+                    hhit = fixed_block((int)gl * SK, head_ok((int)gl));
+                    thit = fixed_block(rl - ((int)gl + 1) * SK, tail_ok((int)gl));
+                }
                 constexpr int NR = SS == 8 ? 6 : 48 / SS;                        // lookups per lane and round
                 uint32_t pkb = 0;
                 if constexpr (SS != 8) {
@@ -735,7 +736,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 bool first = true;
                 for (int ee = e0; __any(ee < e1); ee += NR, first = false) {    // one round unless a slice exceeds NR lookups
                     const bool act = ee < e1;
-                    uint32_t hA = 0, hH = 0;                                     // bit j: lookup ee + j met an anchor code / a code of the ALL index
+                    uint32_t hA = 0;                                             // bit j: lookup ee + j met an anchor code
                     if constexpr (SS == 8) {
                         // blocks do not overlap: codes straight from the text, 48 bytes (13 dwords) per round
                         const uint32_t src = roff + 8u * (uint32_t)(act ? ee : 0), w = src & ~3u, sh8 = (src & 3u) * 8u;
@@ -746,8 +747,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                         for (int j = 0; j < NR; j++) {
                             const uint32_t c2 = code8x2_of(__builtin_amdgcn_alignbit(D[2 * j + 1], D[2 * j], sh8),
                                                            __builtin_amdgcn_alignbit(D[2 * j + 2], D[2 * j + 1], sh8));
-                            const uint32_t two = (S.bm2[c2 >> 5] >> (c2 & 30u)) & 3u;
-                            hA |= (two & 1u) << j; hH |= (two >> 1) << j;
+                            hA |= (((uint32_t)S.bmA[c2 >> 4] >> ((c2 >> 1) & 7u)) & 1u) << j;
                         }
                     } else {
                         const uint32_t bit = act ? 2u * SS * (uint32_t)ee : 0u;  // packed stream: 2 bits per base
@@ -759,21 +759,19 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                                        R2 = __builtin_amdgcn_alignbit(W[3], W[2], bo), R3 = __builtin_amdgcn_alignbit(W[4], W[3], bo);
 #pragma unroll
                         for (int j = 0; j < NR; j++) {
+                            // five instructions and a byte from LDS per lookup: window, byte index, bit index, bit, pile up
                             const int b = 2 * SS * j, wj = b >> 5;
                             const uint32_t lo = wj == 0 ? R0 : wj == 1 ? R1 : R2, hi = wj == 0 ? R1 : wj == 1 ? R2 : R3;
-                            const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(b & 31)) & 0xFFFFu;
-                            const uint32_t two = (S.bm2[win >> 4] >> ((win & 15u) << 1)) & 3u;
-                            hA |= (two & 1u) << j; hH |= (two >> 1) << j;
+                            const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(b & 31));   // the code is its low 16 bits
+                            hA |= (((uint32_t)S.bmA[(win >> 3) & 0x1FFFu] >> (win & 7u)) & 1u) << j;
                         }
                     }
                     const int nv = act ? (e1 - ee < NR ? e1 - ee : NR) : 0;
-                    const uint32_t vm = (1u << nv) - 1u;                        // nv <= 24
-                    hA &= vm;
-                    hH &= vm & (uint32_t)(ee < 64 ? headpat >> ee : 0ull);
-                    const bool th = first && thit;
+                    hA &= (1u << nv) - 1u;                                      // nv <= 24
+                    const bool hh = first && hhit, th = first && thit;
                     // one queue reservation per wave and round, then every lane writes its own candidates
                     // (read | position << 16, kind << 16; P4a adds the code)
-                    const uint32_t c = (uint32_t)__popc(hA) + (uint32_t)__popc(hH) + (th ? 1u : 0u);
+                    const uint32_t c = (uint32_t)__popc(hA) + (hh ? 1u : 0u) + (th ? 1u : 0u);
                     const uint32_t inc = kvq_wave_incl_scan(c);
                     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                     if (tot) {
@@ -783,24 +781,24 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                             if (idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)(SS * (ee + j)) << 16), 0u);   // beyond the cap: dropped, the stretch is redone in halves
                             idx++;
                         }
-                        while (hH) {
-                            const int j = __ffs((int)hH) - 1; hH &= hH - 1u;
-                            if (idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)(SS * (ee + j)) << 16), 1u << 16);
-                            idx++;
-                        }
-                        if (th && idx < ST_QW) q1[idx] = make_uint2(k | (tpp << 16), 1u << 16);
+                        if (hh) { if (idx < ST_QW) q1[idx] = make_uint2(k | ((gl * SK) << 16), 1u << 16); idx++; }
+                        if (th && idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)(rl - ((int)gl + 1) * SK) << 16), 1u << 16);
                         qn += tot;
                     }
                 }
-                // groups narrower than e+1 lanes: the remaining tail blocks, one push round each
+                // groups narrower than e+1 lanes: the remaining head and tail blocks, one push round each
                 for (int t = (int)G; t <= me_; t += (int)G) {
-                    bool hit; uint32_t pp;
-                    tail_block(t + (int)gl, hit, pp);
-                    const uint64_t mm = __ballot(hit);
-                    if (mm) {
-                        const uint32_t idx = qn + (uint32_t)__popcll(mm & kvq_lanemask_lt());
-                        if (hit && idx < ST_QW) q1[idx] = make_uint2(k | (pp << 16), 1u << 16);
-                        qn += (uint32_t)__popcll(mm);
+                    const int jj = t + (int)gl;
+#pragma unroll
+                    for (int side = 0; side < 2; side++) {
+                        const int pp = side ? rl - (jj + 1) * SK : jj * SK;
+                        const bool hit = fixed_block(pp, side ? tail_ok(jj) : head_ok(jj));
+                        const uint64_t mm = __ballot(hit);
+                        if (mm) {
+                            const uint32_t idx = qn + (uint32_t)__popcll(mm & kvq_lanemask_lt());
+                            if (hit && idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)pp << 16), 1u << 16);
+                            qn += (uint32_t)__popcll(mm);
+                        }
                     }
                 }
                 STAMP(5);
