@@ -221,7 +221,8 @@ def main():
     try:
         with open(os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')) as f:
             pmc = json.load(f)
-        if pmc.get('reads_per_gpu') == n and pmc.get('kernel') == out['roofline']['kernel']:
+        if (pmc.get('reads_per_gpu') == n and pmc.get('kernel') == out['roofline']['kernel'] and
+                pmc.get('launches_per_step') == out['roofline']['launches_per_step']):
             out['roofline']['traffic'] = pmc['hbm_bytes_per_launch']
             out['roofline']['traffic_source'] = 'profiles/round1_pmc_traffic.json'
     except (IOError, ValueError):

@@ -39,17 +39,69 @@ static KvqResultLayout kvq_result_layout(uint64_t n, uint64_t blob_bytes)
     return L;
 }
 
-// one wave per hit: the five columns, the closing offset, and the hit bytes moved from where
-// kvq_fold_hits left them to their place in canonical order
+// ---- order by buckets (the usual case) -------------------------------------------------------
+// Hits spread over the stream roughly evenly (a few per thousand reads), so a counting sort into
+// about n buckets of equal file_pos width leaves almost every bucket with zero to a few hits,
+// which one thread puts in order by insertion.  Five small kernels instead of the six passes of
+// a comparison sort over the whole array.  A bucket with more than KVQ_BUCKET_MAX hits (hits
+// crowded into a corner of the stream) raises a flag and the host orders the scan with the merge
+// sort below instead.
+#define KVQ_BUCKET_MAX 32u
+
+struct KvqBucketPlan { int64_t lo; uint32_t shift, nb; };       // bucket = (file_pos - lo) >> shift, nb buckets
+
 __global__ void __launch_bounds__(256)
-kvq_gather_results(const KvqHit *__restrict__ sorted, uint32_t n, const uint8_t *__restrict__ blob_in,
+kvq_bucket_count(const KvqHit *__restrict__ arena, uint32_t n, KvqBucketPlan B, uint32_t *__restrict__ cnt)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < n) atomicAdd(&cnt[1u + (uint32_t)((uint64_t)(arena[h].fpos - B.lo) >> B.shift)], 1u);
+}
+
+__global__ void __launch_bounds__(256)
+kvq_bucket_scatter(const KvqHit *__restrict__ arena, uint32_t n, KvqBucketPlan B, const uint32_t *__restrict__ start,
+                   uint32_t *__restrict__ fill, uint32_t *__restrict__ idx)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n) return;
+    const uint32_t b = (uint32_t)((uint64_t)(arena[h].fpos - B.lo) >> B.shift);
+    idx[start[b] + atomicAdd(&fill[b], 1u)] = h;
+}
+
+// one thread per bucket: insertion sort of its (few) hit numbers
+__global__ void __launch_bounds__(256)
+kvq_bucket_sort(const KvqHit *__restrict__ arena, KvqBucketPlan B, const uint32_t *__restrict__ start, uint32_t *__restrict__ idx,
+                uint32_t *__restrict__ crowded)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B.nb) return;
+    const uint32_t s0 = start[b], m = start[b + 1] - s0;
+    if (m < 2u) return;
+    if (m > KVQ_BUCKET_MAX) { *crowded = 1u; return; }
+    const KvqHitBefore before;
+    for (uint32_t i = 1; i < m; i++) {
+        const uint32_t x = idx[s0 + i]; const KvqHit hx = arena[x];
+        uint32_t j = i;
+        while (j > 0u && before(hx, arena[idx[s0 + j - 1u]])) { idx[s0 + j] = idx[s0 + j - 1u]; j--; }
+        idx[s0 + j] = x;
+    }
+}
+
+struct KvqHitBytesAt {
+    const KvqHit *arena;
+    __host__ __device__ long long operator()(uint32_t h) const { const int l = arena[h].length; return l > 0 ? (long long)l : 0ll; }
+};
+
+// one wave per hit: the five columns, the closing offset, and the hit bytes moved from where
+// kvq_fold_hits left them to their place in canonical order; hit i is arena[order[i]] (order == nullptr: arena[i])
+__global__ void __launch_bounds__(256)
+kvq_gather_results(const KvqHit *__restrict__ arena, const uint32_t *__restrict__ order, uint32_t n, const uint8_t *__restrict__ blob_in,
                    uint8_t *__restrict__ res, KvqResultLayout L)
 {
     const int lane = kvq_lane();
     const uint32_t per = (blockDim.x >> 6) * gridDim.x;
     long long *off = reinterpret_cast<long long *>(res + L.hitseq_off);
     for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += per) {
-        const KvqHit h = sorted[i];
+        const KvqHit h = arena[order ? order[i] : i];
         const long long at = off[i];
         const int len = h.length > 0 ? h.length : 0;
         if (lane == 0) {
@@ -66,24 +118,58 @@ kvq_gather_results(const KvqHit *__restrict__ sorted, uint32_t n, const uint8_t 
     }
 }
 
-// enqueue sort + offsets + gather for the n hits of the arena; *tmp / *sorted are grow-only scratch
+// enqueue ordering + offsets + gather for the n hits of the arena whose file positions lie in
+// [lo, hi); tmp / sorted are grow-only scratch.  by_buckets: the counting sort (*d_crowded is
+// raised when it gave up; the caller then calls again with by_buckets = false)
 static int kvq_order_results(hipStream_t stream, const KvqHit *arena, uint32_t n, const uint8_t *blob_in,
-                             DevBuf &tmp, DevBuf &sorted, uint8_t *res, const KvqResultLayout &L)
+                             DevBuf &tmp, DevBuf &sorted, uint8_t *res, const KvqResultLayout &L,
+                             bool by_buckets, int64_t lo, int64_t hi, uint32_t *d_crowded)
 {
     if (n == 0) return KVQ_OK;
     int rc;
+    long long *off = reinterpret_cast<long long *>(res + L.hitseq_off);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 3) / 4, 8192);
+    if (by_buckets) {
+        KvqBucketPlan B; B.lo = lo;
+        uint32_t want = 256; while (want < n && want < (1u << 22)) want <<= 1;
+        const uint64_t span = (uint64_t)(hi > lo ? hi - lo : 1);
+        B.shift = 0; while ((span >> B.shift) >= (uint64_t)want) B.shift++;
+        B.nb = (uint32_t)(span >> B.shift) + 1u;                           // <= want
+        // scratch: start[nb + 1] | fill[nb] | idx[n] | scan storage
+        const size_t start_b = (((size_t)B.nb + 1) * 4 + 255) & ~(size_t)255, fill_b = ((size_t)B.nb * 4 + 255) & ~(size_t)255,
+                     idx_b = ((size_t)n * 4 + 255) & ~(size_t)255;
+        size_t need_scan_a = 0, need_scan_b = 0;
+        uint32_t *null32 = nullptr;
+        KVQ_HIP(rocprim::inclusive_scan(nullptr, need_scan_a, null32, null32, (size_t)B.nb, rocprim::plus<uint32_t>(), stream));
+        auto lens0 = rocprim::make_transform_iterator(null32, KvqHitBytesAt{ arena });
+        KVQ_HIP(rocprim::exclusive_scan(nullptr, need_scan_b, lens0, off, 0ll, (size_t)n, rocprim::plus<long long>(), stream));
+        const size_t scan_b = std::max(need_scan_a, need_scan_b) + 256;
+        if ((rc = tmp.ensure(start_b + fill_b + idx_b + scan_b))) return rc;
+        uint8_t *base = (uint8_t *)tmp.p;
+        uint32_t *start = (uint32_t *)base, *fill = (uint32_t *)(base + start_b), *idx = (uint32_t *)(base + start_b + fill_b);
+        void *scan_tmp = base + start_b + fill_b + idx_b;
+        KVQ_HIP(hipMemsetAsync(base, 0, start_b + fill_b, stream));
+        KVQ_HIP(hipMemsetAsync(d_crowded, 0, 4, stream));
+        hipLaunchKernelGGL(kvq_bucket_count, dim3((n + 255) / 256), dim3(256), 0, stream, arena, n, B, start);
+        KVQ_HIP(rocprim::inclusive_scan(scan_tmp, need_scan_a, start + 1, start + 1, (size_t)B.nb, rocprim::plus<uint32_t>(), stream));
+        hipLaunchKernelGGL(kvq_bucket_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, arena, n, B, (const uint32_t *)start, fill, idx);
+        hipLaunchKernelGGL(kvq_bucket_sort, dim3((B.nb + 255) / 256), dim3(256), 0, stream, arena, B, (const uint32_t *)start, idx, d_crowded);
+        auto lens = rocprim::make_transform_iterator((const uint32_t *)idx, KvqHitBytesAt{ arena });
+        KVQ_HIP(rocprim::exclusive_scan(scan_tmp, need_scan_b, lens, off, 0ll, (size_t)n, rocprim::plus<long long>(), stream));
+        hipLaunchKernelGGL(kvq_gather_results, dim3(blocks), dim3(256), 0, stream, arena, (const uint32_t *)idx, n, blob_in, res, L);
+        KVQ_HIP(hipGetLastError());
+        return KVQ_OK;
+    }
     if ((rc = sorted.ensure((size_t)n * sizeof(KvqHit)))) return rc;
     KvqHit *out = sorted.as<KvqHit>();
     size_t need_sort = 0, need_scan = 0;
     auto lens = rocprim::make_transform_iterator(out, KvqHitBytes());
-    long long *off = reinterpret_cast<long long *>(res + L.hitseq_off);
     KVQ_HIP(rocprim::merge_sort(nullptr, need_sort, arena, out, (size_t)n, KvqHitBefore(), stream));
     KVQ_HIP(rocprim::exclusive_scan(nullptr, need_scan, lens, off, 0ll, (size_t)n, rocprim::plus<long long>(), stream));
     if ((rc = tmp.ensure(std::max(need_sort, need_scan) + 256))) return rc;
     KVQ_HIP(rocprim::merge_sort(tmp.p, need_sort, arena, out, (size_t)n, KvqHitBefore(), stream));
     KVQ_HIP(rocprim::exclusive_scan(tmp.p, need_scan, lens, off, 0ll, (size_t)n, rocprim::plus<long long>(), stream));
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 3) / 4, 8192);
-    hipLaunchKernelGGL(kvq_gather_results, dim3(blocks), dim3(256), 0, stream, (const KvqHit *)out, n, blob_in, res, L);
+    hipLaunchKernelGGL(kvq_gather_results, dim3(blocks), dim3(256), 0, stream, (const KvqHit *)out, (const uint32_t *)nullptr, n, blob_in, res, L);
     KVQ_HIP(hipGetLastError());
     return KVQ_OK;
 }

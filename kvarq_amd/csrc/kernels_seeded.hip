@@ -619,6 +619,21 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                         // behind the slice are masked off below, the buffer has slack behind its end)
                         uint64_t m = 0;
                         int sh = -lead;
+                        {
+                            // the first 48 bytes in one go (twelve loads travel together; a 150 bp read's
+                            // slice needs no more), whatever is left in rounds of 16
+                            uint32_t q[12];
+#pragma unroll
+                            for (int t = 0; t < 12; t++) q[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
+#pragma unroll
+                            for (int u = 0; u < 3; u++) {
+                                const uint32_t g16 = kvq_flags16(good_flags(q[4 * u], addk), good_flags(q[4 * u + 1], addk),
+                                                                 good_flags(q[4 * u + 2], addk), good_flags(q[4 * u + 3], addk));
+                                const int shu = sh + 16 * u;
+                                m |= shu >= 0 ? ((uint64_t)g16 << shu) : ((uint64_t)g16 >> (-shu));
+                            }
+                            w += 48u; sh += 48;
+                        }
                         for (; w < abs1; w += 16u, sh += 16) {
                             uint32_t q[4];
 #pragma unroll
@@ -704,11 +719,8 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 // head block counts as head block only); their candidates join the first round's push
                 auto head_ok = [&](int jj) { return mine && jj <= me_ && (jj + 1) * SK <= rl; };
                 auto tail_ok = [&](int jj) { const int pp = rl - (jj + 1) * SK; return mine && jj <= me_ && pp >= 0 && !((pp % SK) == 0 && pp <= me_ * SK); };
-                bool hhit = false, thit = false;
-                if (__any(mine)) {
-                    hhit = fixed_block((int)gl * SK, head_ok((int)gl));
-                    thit = fixed_block(rl - ((int)gl + 1) * SK, tail_ok((int)gl));
-                }
+                const bool hhit = fixed_block((int)gl * SK, head_ok((int)gl));
+                const bool thit = fixed_block(rl - ((int)gl + 1) * SK, tail_ok((int)gl));
                 constexpr int NR = SS == 8 ? 6 : 48 / SS;                        // lookups per lane and round
                 uint32_t pkb = 0;
                 if constexpr (SS != 8) {
@@ -721,15 +733,22 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                         nw = (rl + 15) >> 4;
                     }
                     pkb = (sscore_l + 3u) & ~3u;
-                    for (int i = (int)gl; __any(i < nw); i += (int)G) {
-                        if (i < nw) {
-                            const uint32_t src = roff + 16u * (uint32_t)i, w = src & ~3u, sh8 = (src & 3u) * 8u;
-                            uint32_t d[5];
+                    // (three words per lane and round: their fifteen loads travel together)
+                    for (int i0 = (int)gl; __any(i0 < nw); i0 += 3 * (int)G) {
+                        uint32_t d[3][5]; const uint32_t sh8 = (roff & 3u) * 8u;
 #pragma unroll
-                            for (int t = 0; t < 5; t++) d[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
-                            const uint32_t c01 = code8x2_of(__builtin_amdgcn_alignbit(d[1], d[0], sh8), __builtin_amdgcn_alignbit(d[2], d[1], sh8));
-                            const uint32_t c23 = code8x2_of(__builtin_amdgcn_alignbit(d[3], d[2], sh8), __builtin_amdgcn_alignbit(d[4], d[3], sh8));
-                            *reinterpret_cast<uint32_t *>(&S.buf[pkb + 4u * (uint32_t)i]) = (c01 >> 1) | (c23 << 15);
+                        for (int u = 0; u < 3; u++) {
+                            const int i = i0 + u * (int)G;
+                            const uint32_t w = (roff + 16u * (uint32_t)(i < nw ? i : 0)) & ~3u;
+#pragma unroll
+                            for (int t = 0; t < 5; t++) d[u][t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 3; u++) {
+                            const int i = i0 + u * (int)G;
+                            const uint32_t c01 = code8x2_of(__builtin_amdgcn_alignbit(d[u][1], d[u][0], sh8), __builtin_amdgcn_alignbit(d[u][2], d[u][1], sh8));
+                            const uint32_t c23 = code8x2_of(__builtin_amdgcn_alignbit(d[u][3], d[u][2], sh8), __builtin_amdgcn_alignbit(d[u][4], d[u][3], sh8));
+                            if (i < nw) *reinterpret_cast<uint32_t *>(&S.buf[pkb + 4u * (uint32_t)i]) = (c01 >> 1) | (c23 << 15);
                         }
                     }
                 }

@@ -559,11 +559,26 @@ static int finish_once(kvq_scan *s)
         s->pin_cap = want;
     }
     if ((rc = s->d_result.ensure(L.total + 256))) return rc;
-    if ((rc = kvq_order_results(s->stream, s->d_arena.as<KvqHit>(), n_hits, s->d_blob.as<uint8_t>(), s->d_sort_tmp, s->d_sorted,
-                                s->d_result.as<uint8_t>(), L))) return rc;
-    if (n_hits) KVQ_HIP(hipMemcpyAsync(s->pin, s->d_result.p, L.total, hipMemcpyDeviceToHost, s->stream));
-    KVQ_HIP(hipMemcpyAsync(s->pin + L.total, s->d_ctr, ctr_b, hipMemcpyDeviceToHost, s->stream));
-    KVQ_HIP(hipStreamSynchronize(s->stream));
+    // file positions of this scan lie in [lo, hi)
+    int64_t lo = 0, hi = 1;
+    for (size_t b = 0; b < s->batches.size(); b++) {
+        const int64_t a = s->batches[b].fpos_base, e = a + s->batches[b].nbytes;
+        if (b == 0 || a < lo) lo = a;
+        if (b == 0 || e > hi) hi = e;
+    }
+    static const bool no_buckets = getenv("KVQ_ORDER") && !strcmp(getenv("KVQ_ORDER"), "mergesort");
+    unsigned int *d_crowded = reinterpret_cast<unsigned int *>((char *)s->d_small.p + 32);
+    unsigned int *h_crowded = reinterpret_cast<unsigned int *>(s->pin_small + 32);
+    *h_crowded = 0;
+    for (int attempt = no_buckets ? 1 : 0; attempt < 2; attempt++) {
+        if ((rc = kvq_order_results(s->stream, s->d_arena.as<KvqHit>(), n_hits, s->d_blob.as<uint8_t>(), s->d_sort_tmp, s->d_sorted,
+                                    s->d_result.as<uint8_t>(), L, attempt == 0, lo, hi, d_crowded))) return rc;
+        if (n_hits) KVQ_HIP(hipMemcpyAsync(s->pin, s->d_result.p, L.total, hipMemcpyDeviceToHost, s->stream));
+        if (n_hits && attempt == 0) KVQ_HIP(hipMemcpyAsync(h_crowded, d_crowded, 4, hipMemcpyDeviceToHost, s->stream));
+        KVQ_HIP(hipMemcpyAsync(s->pin + L.total, s->d_ctr, ctr_b, hipMemcpyDeviceToHost, s->stream));
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        if (attempt == 1 || !n_hits || !*h_crowded) break;       // (crowded buckets: once more, with the comparison sort)
+    }
     memcpy(s->h_ctr.data(), s->pin + L.total, ctr_b);
     if (!n_hits) memset(s->pin + L.hitseq_off, 0, 8);
     s->res = L; s->n_hits = n_hits;

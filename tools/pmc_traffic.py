@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of the seed-filter kernel from two rocprofv3 --pmc passes.
+
+usage: python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <reads per GPU> <record bytes> > profiles/roundN_pmc_traffic.json
+
+Both passes run the same command (`python bench.py --steps 2 --warmup 1 --no-cpu-baseline`).
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts half of the bytes of a
+16-byte-per-lane streaming read, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE * 1024 is exact.
+"""
+import csv, glob, json, sys
+
+def per_launch(root, counter, sub='kvq_scan_seeded'):
+    acc = {}
+    for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if sub in r['Kernel_Name'] and r['Counter_Name'] == counter:
+                    acc[r['Dispatch_Id']] = acc.get(r['Dispatch_Id'], 0.0) + float(r['Counter_Value'])
+    return [acc[k] for k in sorted(acc, key=int)]
+
+def main():
+    fdir, wdir, reads, rb = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    f = per_launch(fdir, 'FETCH_SIZE'); w = per_launch(wdir, 'WRITE_SIZE')
+    steps = 3                                    # --steps 2 --warmup 1
+    launches_per_step = len(f) // steps
+    fm = sum(f) / len(f); wm = sum(w) / len(w)
+    alg = reads * rb / launches_per_step
+    rd = 2.0 * fm * 1024.0; wr = wm * 1024.0
+    out = {
+        'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (separate passes)',
+        'kernel': 'kvq_scan_seeded', 'reads_per_gpu': reads, 'launches_per_step': launches_per_step,
+        'note': 'gfx950: FETCH_SIZE counts 1/2 of the bytes of a 16-B-per-lane streaming read (MI355X_MICROARCH.md, HBM section), '
+                'so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact. Per-launch values are the mean over the launches of the run. '
+                'The excess over the algorithmic bytes is the 4160-byte look-ahead every 32000-byte tile re-reads (1.13x) plus seed-index and table lookups.',
+        'FETCH_SIZE_KB_per_launch_raw': f, 'FETCH_SIZE_KB_mean': fm,
+        'WRITE_SIZE_KB_per_launch_raw': w, 'WRITE_SIZE_KB_mean': wm,
+        'algorithmic_bytes_per_launch': alg,
+        'hbm_read_bytes_per_launch': rd, 'hbm_write_bytes_per_launch': wr, 'hbm_bytes_per_launch': rd + wr,
+        'traffic_over_algorithmic': (rd + wr) / alg,
+    }
+    print(json.dumps(out, indent=1))
+
+if __name__ == '__main__':
+    main()
