@@ -147,6 +147,26 @@ def test_hit_arena_overflow_is_transparent():
     s.close(); t.close(); d.free()
 
 
+def test_many_hits_per_read_come_back_in_reference_order():
+    """dozens of hits share one file position (the bucket ordering gives up and the comparison sort takes
+    over): order, hit bytes and counters still equal the oracle's"""
+    read = 'ACG' * 60
+    data = np.frombuffer(cases.rec('x', read, 'I' * len(read)) * 300 + cases.rec('y', 'TTTTACGTTTTTTTTT', 'I' * 16) * 50, dtype=np.uint8)
+    seqs = [b'ACG', b'CGA', b'GAC', b'TTACG']
+    cfg = dict(cases.DEFAULTS, minreadlength=10)
+    o = O.scan_memory(data, seqs, fold=True, **dict(cfg, nthreads=4))
+    t = scan.Table(seqs, **cfg)
+    s = scan.Scanner(t)
+    d = scan.DeviceBuffer(data.nbytes)
+    d.upload(data)
+    s.scan_device(d.ptr, data.nbytes, scan.chunk_offsets(data))
+    r = s.finish()
+    assert r['n_hits'] == len(o['hits']) > 300 * 170
+    assert tuple(r['hits']) == tuple(o['hits']) and r['hitseqs'] == o['hitseqs']
+    assert r['coverage'].tolist() == o['coverage'] and r['mutations'].tolist() == o['mutations']
+    s.close(); t.close(); d.free()
+
+
 def test_concurrent_findseqs_is_refused_and_stop_works(tmp_path):
     import threading, time
     p = tmp_path / 'big.fastq'

@@ -18,11 +18,11 @@ def main():
     rows.sort()
     # the last 4 main launches and everything between the first of them and the end of the step
     mains = [i for i, r in enumerate(rows) if 'kvq_scan_seeded' in r[2]]
-    if len(mains) < 8:
+    if len(mains) < 4:
         print('too few launches'); return
-    lo = mains[-4]
+    lo = mains[-int(sys.argv[2]) if len(sys.argv) > 2 else -2]
     # walk back to the memsets/expand kernels that belong to the first batch
-    while lo > 0 and rows[lo - 1][0] > rows[mains[-5]][1] and not rows[lo - 1][2].startswith('kvq_gather'):
+    while lo > 0 and rows[lo - 1][0] > rows[mains[(-int(sys.argv[2]) if len(sys.argv) > 2 else -2) - 1]][1] and not rows[lo - 1][2].startswith('kvq_gather'):
         lo -= 1
     t0 = rows[lo][0]; prev_end = t0
     for s, e, n in rows[lo:]:
