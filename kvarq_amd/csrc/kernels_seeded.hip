@@ -178,7 +178,8 @@ struct SeededLds {
     uint2    q1[ST_QCAP];                // candidate: x = rec | pos << 16, y = code | kind << 16
     uint32_t q2[ST_Q2CAP];               // work item: candidate << 22 | index entry
     uint32_t rinfo[ST_RCAP];             // read offset in buf | rl << 16
-    uint32_t wtot[ST_WAVES], wown[ST_WAVES];   // newlines per wave: all, and those the tile owns
+    __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];   // newlines per wave: all ...
+    __attribute__((aligned(16))) uint32_t wown[ST_WAVES];   // ... and those the tile owns
     uint32_t longest_p1, records, fallback;
 };
 
@@ -453,6 +454,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
     // the empty block in front of the tile), so the scan works on registers and needs no barrier
     // behind the LDS fill
     static_assert(ST_ROUNDS * 16u == ST_BLK, "one scan block per thread");
+    static_assert(ST_WAVES == 8, "the wave totals are read as two uint4 each");
     uint4 pre[ST_ROUNDS];
     const uint32_t blk = (uint32_t)tid * ST_BLK;                           // the block's place in buf
     const uint32_t toff = blk - ST_PRE;                                    // ... and in the tile's text (tid >= 1)
@@ -517,8 +519,16 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         uint32_t n_all = 0, n_own_all = 0;
         {
             uint32_t mine = 0;
+            uint32_t tot[ST_WAVES], own[ST_WAVES];
+            {
+                // four 16-byte LDS reads instead of sixteen dword reads
+                const uint4 a0 = reinterpret_cast<const uint4 *>(S.wtot)[0], a1 = reinterpret_cast<const uint4 *>(S.wtot)[1];
+                const uint4 b0 = reinterpret_cast<const uint4 *>(S.wown)[0], b1 = reinterpret_cast<const uint4 *>(S.wown)[1];
+                tot[0] = a0.x; tot[1] = a0.y; tot[2] = a0.z; tot[3] = a0.w; tot[4] = a1.x; tot[5] = a1.y; tot[6] = a1.z; tot[7] = a1.w;
+                own[0] = b0.x; own[1] = b0.y; own[2] = b0.z; own[3] = b0.w; own[4] = b1.x; own[5] = b1.y; own[6] = b1.z; own[7] = b1.w;
+            }
 #pragma unroll
-            for (int w = 0; w < ST_WAVES; w++) { const uint32_t t = S.wtot[w]; if (w == (int)wave) mine = n_all; n_all += t; n_own_all += S.wown[w]; }
+            for (int w = 0; w < ST_WAVES; w++) { if (w == (int)wave) mine = n_all; n_all += tot[w]; n_own_all += own[w]; }
             uint32_t n = mine + incl - cnt;
             if (cnt) {
 #pragma unroll
@@ -671,14 +681,34 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                     }
                 }
                 // ordered tree merge over the G lanes of the read
-                for (uint32_t d = 1; d < G; d <<= 1) {
-                    Seg B;
-                    B.len = __shfl_xor(sg.len, (int)d, 64); B.pre = __shfl_xor(sg.pre, (int)d, 64); B.suf = __shfl_xor(sg.suf, (int)d, 64);
-                    B.best = __shfl_xor(sg.best, (int)d, 64); B.bstart = __shfl_xor(sg.bstart, (int)d, 64); B.beg = 0;
-                    if ((gl & d) == 0) sg = seg_merge(sg, B);
+                if (G == 4u) {
+                    // the common group width: neighbours inside a quad, by DPP (no LDS traffic)
+#define KVQ_QUAD(v, ctl) __builtin_amdgcn_update_dpp(0, (v), (ctl), 0xf, 0xf, false)
+                    {
+                        Seg B;                                                       // lane ^ 1: quad_perm [1,0,3,2]
+                        B.len = KVQ_QUAD(sg.len, 0xB1); B.pre = KVQ_QUAD(sg.pre, 0xB1); B.suf = KVQ_QUAD(sg.suf, 0xB1);
+                        B.best = KVQ_QUAD(sg.best, 0xB1); B.bstart = KVQ_QUAD(sg.bstart, 0xB1); B.beg = 0;
+                        if ((gl & 1u) == 0) sg = seg_merge(sg, B);
+                    }
+                    {
+                        Seg B;                                                       // lane ^ 2: quad_perm [2,3,0,1]
+                        B.len = KVQ_QUAD(sg.len, 0x4E); B.pre = KVQ_QUAD(sg.pre, 0x4E); B.suf = KVQ_QUAD(sg.suf, 0x4E);
+                        B.best = KVQ_QUAD(sg.best, 0x4E); B.bstart = KVQ_QUAD(sg.bstart, 0x4E); B.beg = 0;
+                        if ((gl & 2u) == 0) sg = seg_merge(sg, B);
+                    }
+                    rl = KVQ_QUAD(sg.best, 0x00);                                   // lane 0 of the quad: quad_perm [0,0,0,0]
+                    roff = sread + (uint32_t)KVQ_QUAD(sg.bstart, 0x00);              // 1070
+#undef KVQ_QUAD
+                } else {
+                    for (uint32_t d = 1; d < G; d <<= 1) {
+                        Seg B;
+                        B.len = __shfl_xor(sg.len, (int)d, 64); B.pre = __shfl_xor(sg.pre, (int)d, 64); B.suf = __shfl_xor(sg.suf, (int)d, 64);
+                        B.best = __shfl_xor(sg.best, (int)d, 64); B.bstart = __shfl_xor(sg.bstart, (int)d, 64); B.beg = 0;
+                        if ((gl & d) == 0) sg = seg_merge(sg, B);
+                    }
+                    rl = __shfl(sg.best, lane & ~(int)(G - 1u), 64);
+                    roff = sread + (uint32_t)__shfl(sg.bstart, lane & ~(int)(G - 1u), 64);             // 1070
                 }
-                rl = __shfl(sg.best, lane & ~(int)(G - 1u), 64);
-                roff = sread + (uint32_t)__shfl(sg.bstart, lane & ~(int)(G - 1u), 64);                 // 1070
                 if (gl == 0) {
                     if (rl < KVQ_RL_BINS) atomicAdd(&S.hist[rl], 1u);                                 // 394-402
                     atomicMax(&S.longest_p1, (uint32_t)(rl + 1));
