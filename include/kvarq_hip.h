@@ -128,6 +128,17 @@ int32_t kvq_scan_device(kvq_scan *s, const void *d_data, int64_t nbytes,
 int32_t kvq_scan_host(kvq_scan *s, const void *h_data, int64_t nbytes,
                       const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base);
 
+/* the same without waiting for the copy: one host batch is in flight at a time, so that the
+ * caller can fill its next buffer (fread / inflate) while this one is copied and scanned.
+ * h_data must stay untouched until kvq_scan_host_copied(s) has returned (or the next
+ * kvq_scan_host_async / kvq_scan_host_drain / kvq_scan_finish).  kvq_scan_host_drain waits for the
+ * batch in flight and settles it (a batch whose record-split speculation failed validation is
+ * scanned again with the exhaustive kernels while its text is still staged). */
+int32_t kvq_scan_host_async(kvq_scan *s, const void *h_data, int64_t nbytes,
+                            const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base);
+int32_t kvq_scan_host_copied(kvq_scan *s);
+int32_t kvq_scan_host_drain(kvq_scan *s);
+
 /* wait for the device, fold hits into the counters, bring hits (canonical
  * order), hit bytes and counters to the host.  On a malformed
  * record returns KVQ_ERR_FORMAT with the reference's message

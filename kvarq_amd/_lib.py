@@ -48,6 +48,9 @@ PROTOTYPES = {
     'kvq_chunk_offsets': (i64, [vp, i64, P(i64), i64]),
     'kvq_scan_device': (i32, [vp, vp, i64, P(i64), i64, i64]),
     'kvq_scan_host': (i32, [vp, vp, i64, P(i64), i64, i64]),
+    'kvq_scan_host_async': (i32, [vp, vp, i64, P(i64), i64, i64]),
+    'kvq_scan_host_copied': (i32, [vp]),
+    'kvq_scan_host_drain': (i32, [vp]),
     'kvq_scan_finish': (i32, [vp]),
     'kvq_scan_n_hits': (i64, [vp]),
     'kvq_scan_hit_seq_nr': (P(i32), [vp]),

@@ -238,9 +238,12 @@ static const int64_t BATCH_BYTES = 64ll << 20;     // new stream bytes per batch
 
 // Walk the files once: Sink::batch(data, nbytes, chunk offsets, nchunks, fpos,
 // parsed, total) is called for every run of whole chunks, in stream order.
+// pin2 (optional): a second buffer of the same size; the walk then alternates between the two
+// after every batch, so that the sink may still be reading the batch it was handed last (the
+// sink must be done with a batch when it is handed the next one)
 template <class Sink>
 static int stream_batches(Sink &sink, const char *const *files, int nfiles, uint8_t *pin, int64_t pin_cap,
-                          int64_t *parsed, int64_t *total)
+                          int64_t *parsed, int64_t *total, uint8_t *pin2 = nullptr)
 {
     StreamSource src;
     int rc = src.open(files, nfiles);
@@ -291,11 +294,15 @@ static int stream_batches(Sink &sink, const char *const *files, int nfiles, uint
                                 pin_fpos + batch_begin, src.fpos(), src.total());
                 if (rc) return rc;
             }
-            if (file_finished) break;
-            // carry the unfinished chunk to the front of the buffer
+            if (file_finished) {
+                if (pin2 && !off.empty()) std::swap(pin, pin2);       // the next file starts in the other buffer
+                break;
+            }
+            // carry the unfinished chunk to the front of the (other) buffer
             const int64_t carry = have - cs;
             if (carry >= pin_cap) { kvq_set_error(KVQ_ERR_RUNTIME, "buf_size < fastq->buf_size !"); return KVQ_ERR_RUNTIME; }
-            memmove(pin, pin + cs, (size_t)carry);
+            if (pin2 && !off.empty()) { memcpy(pin2, pin + cs, (size_t)carry); std::swap(pin, pin2); }
+            else memmove(pin, pin + cs, (size_t)carry);
             pin_fpos += cs; fill -= cs; have = carry; cs = 0;
         }
     }
@@ -305,19 +312,23 @@ static int stream_batches(Sink &sink, const char *const *files, int nfiles, uint
 
 // the GPU sink: one kvq_scan_host per batch, live stats after each
 struct ScanSink {
-    kvq_scan *s; std::vector<int64_t> ctr_live;
+    kvq_scan *s; std::vector<int64_t> ctr_live; bool have_live = false; int64_t live_parsed = 0;
     void begin(int64_t total) { live_reset(s->t->nseq, total); ctr_live.resize((size_t)s->t->ctr_len); }
     int batch(const uint8_t *data, int64_t nbytes, const int64_t *off, int64_t nchunks, int64_t fpos, int64_t parsed, int64_t total)
     {
-        int rc = kvq_scan_host(s, data, nbytes, off, nchunks, fpos);
+        // the batch handed over last has been read from its host buffer and scanned by now or soon:
+        // wait for it, publish its counters (engine.stats() may be polling), then enqueue this one and
+        // return, so that the reader fills the other host buffer while this one is copied and scanned
+        int rc = kvq_scan_host_drain(s);
         if (rc) return rc;
-        // live stats (engine.stats() may be polling); also drains the stream before the pinned buffer is reused
-        if (hipStreamSynchronize(s->stream) != hipSuccess ||
-            hipMemcpy(ctr_live.data(), s->d_ctr, (size_t)s->t->ctr_len * 8, hipMemcpyDeviceToHost) != hipSuccess) {
-            kvq_set_error(KVQ_ERR_DEVICE, "device failure during scan"); return KVQ_ERR_DEVICE;
+        if (have_live) {
+            if (hipMemcpy(ctr_live.data(), s->d_ctr, (size_t)s->t->ctr_len * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                kvq_set_error(KVQ_ERR_DEVICE, "device failure during scan"); return KVQ_ERR_DEVICE;
+            }
+            live_from_counters(s->t, ctr_live.data(), live_parsed, total);
         }
-        live_from_counters(s->t, ctr_live.data(), parsed, total);
-        return KVQ_OK;
+        have_live = true; live_parsed = parsed;
+        return kvq_scan_host_async(s, data, nbytes, off, nchunks, fpos);
     }
 };
 
@@ -326,14 +337,18 @@ static int findseqs_pass(kvq_scan *s, const char *const *files, int nfiles, uint
 {
     ScanSink sink; sink.s = s;
     int64_t parsed = 0, total = 0;
-    int rc = stream_batches(sink, files, nfiles, pin, pin_cap, &parsed, &total);
+    const double tp0 = now_ms();
+    int rc = stream_batches(sink, files, nfiles, pin, pin_cap, &parsed, &total, pin + pin_cap);     // two host buffers
+    if (g_timing) fprintf(stderr, "findseqs pass: stream %.1f ms\n", now_ms() - tp0);
     if (rc) return rc;
     s->parsed = parsed; s->total = total;
     {
         std::lock_guard<std::mutex> l(g_live_lock);
         g_live.parsed = parsed; g_live.total = total;
     }
-    return kvq_scan_finish_internal(s);
+    rc = kvq_scan_finish_internal(s);
+    if (rc == KVQ_OK) live_from_counters(s->t, s->h_ctr.data(), parsed, total);     // stats() after the scan == the scan's stats
+    return rc;
 }
 
 // host-only view of the same walk (no GPU): the chunks fastq_read would hand
@@ -372,13 +387,19 @@ extern "C" kvq_scan *kvq_findseqs(const char *const *files, int32_t nfiles,
         return nullptr;
     }
     g_stop = 0; g_sigints = 0;                                         // workhorse.c:1264-1265
+    const double tf0 = now_ms();
     kvq_table *t = kvq_table_create(seqs, seqlens, nseq, nullptr);
     kvq_scan *s = t ? kvq_scan_create(t, nullptr) : nullptr;
-    uint8_t *pin = nullptr;
+    const double tf1 = now_ms();
+    // the two pinned host buffers outlive the call: pinning and unpinning 130 MB costs more than
+    // streaming a 1 GB file through them (only one findseqs runs at a time, g_running)
+    static uint8_t *g_pin = nullptr;
     const int64_t pin_cap = BATCH_BYTES + 2 * KVQ_SCANBUFSIZE;
-    if (s && hipHostMalloc((void **)&pin, (size_t)pin_cap, hipHostMallocDefault) != hipSuccess) {
-        kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for scanning"); pin = nullptr;
+    if (s && !g_pin && hipHostMalloc((void **)&g_pin, (size_t)pin_cap * 2, hipHostMallocDefault) != hipSuccess) {
+        kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for scanning"); g_pin = nullptr;
     }
+    uint8_t *const pin = g_pin;
+    const double tf2 = now_ms();
     if (s && pin) {
         for (int attempt = 0; attempt < 4; attempt++) {
             const int rc = findseqs_pass(s, files, nfiles, pin, pin_cap);
@@ -388,7 +409,9 @@ extern "C" kvq_scan *kvq_findseqs(const char *const *files, int32_t nfiles,
             if (attempt == 3) kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results");
         }
     }
-    if (pin) (void)hipHostFree(pin);
+    const double tf3 = now_ms();
+    if (s && s->stream) (void)hipStreamSynchronize(s->stream);        // nothing may still be reading the host buffers
+    if (g_timing) fprintf(stderr, "findseqs: table+scan %.1f  pinned alloc %.1f  passes %.1f  free %.1f ms\n", tf1 - tf0, tf2 - tf1, tf3 - tf2, now_ms() - tf3);
     g_running = 0;
     if (s) s->t = t;          // the scan owns its table: destroyed with it (kvq_findseqs_free)
     else if (t) kvq_table_destroy(t);

@@ -91,6 +91,8 @@ struct kvq_scan {
     // replay list (device batches) + bookkeeping
     std::vector<Batch> batches;
     bool host_batches = false;
+    int64_t host_pending = -1;           // index of the host batch in flight (kvq_scan_host_async), -1: none
+    hipEvent_t ev_copied = nullptr;      // its text has left the host buffer
     int64_t records = 0;
     int64_t parsed = 0, total = 0;
     // timing

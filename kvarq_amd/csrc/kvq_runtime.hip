@@ -282,6 +282,7 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     if (s->own_ctr && s->d_ctr) (void)hipFree(s->d_ctr);
     if (s->pin) (void)hipHostFree(s->pin);
     if (s->pin_small) (void)hipHostFree(s->pin_small);
+    if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
     DevBuf *bufs[] = { &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_covdiff, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
                        &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
     for (DevBuf *b : bufs) b->release();
@@ -299,7 +300,7 @@ extern "C" int32_t kvq_scan_reset(kvq_scan *s)
     const double tr0 = now_ms();
     KVQ_HIP(hipStreamSynchronize(s->stream));
     drop_events(s);
-    s->batches.clear(); s->host_batches = false; s->records = 0; s->parsed = 0; s->total = 0;
+    s->batches.clear(); s->host_batches = false; s->host_pending = -1; s->records = 0; s->parsed = 0; s->total = 0;
     s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->path_bits = 0; s->n_hits = 0;
     s->pool.used = 0;
     const int rr = reset_device_state(s);
@@ -463,37 +464,73 @@ extern "C" int32_t kvq_scan_device(kvq_scan *s, const void *d_data, int64_t nbyt
     return run_batch(s, (const uint8_t *)d_data, nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1, false);
 }
 
-extern "C" int32_t kvq_scan_host(kvq_scan *s, const void *h_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base)
+// Host batches go through one device staging buffer, one batch in flight: while the GPU copies and
+// scans batch k the caller reads batch k+1 into another host buffer.  kvq_scan_host_drain waits for
+// the batch in flight and settles it: when its seed-filter pass failed validation it is scanned
+// again, exhaustively, while its text is still in the staging buffer.
+extern "C" int32_t kvq_scan_host_drain(kvq_scan *s)
+{
+    KVQ_HIP(hipStreamSynchronize(s->stream));
+    if (s->host_pending < 0) return KVQ_OK;
+    const size_t b = (size_t)s->host_pending;
+    s->host_pending = -1;
+    if (!(s->path_bits & 1)) return KVQ_OK;
+    const unsigned int fail = *reinterpret_cast<const unsigned int *>(s->pin_small + 40);     // copied behind the batch
+    if (!fail) return KVQ_OK;
+    s->batches[b].redone = true;
+    Batch again = s->batches[b]; again.is_redo = true;
+    s->batches.push_back(again);
+    s->path_bits |= 4;
+    int rc = run_batch(s, s->d_stage.as<uint8_t>(), again.nbytes, again.chunk_off.data(), (int64_t)again.chunk_off.size() - 1,
+                       again.fpos_base, s->batches.size() - 1, true);
+    if (rc) return rc;
+    KVQ_HIP(hipStreamSynchronize(s->stream));
+    return KVQ_OK;
+}
+
+// enqueue one host batch and return; h_data must stay untouched until kvq_scan_host_copied(s)
+// (or the next kvq_scan_host_async / kvq_scan_host_drain / kvq_scan_finish) has returned
+extern "C" int32_t kvq_scan_host_async(kvq_scan *s, const void *h_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base)
 {
     kvq_clear_error();
     if (nbytes <= 0) return KVQ_OK;
-    // the staging buffer is reused: the previous batch must have drained
-    KVQ_HIP(hipStreamSynchronize(s->stream));
-    s->pool.used = 0;                      // every earlier batch has drained: recycle its tables
-    int rc = s->d_stage.ensure((size_t)nbytes + 64); if (rc) return rc;
+    int rc = kvq_scan_host_drain(s); if (rc) return rc;          // the staging buffer and the table pool are free again
+    s->pool.used = 0;
+    if ((rc = s->d_stage.ensure((size_t)nbytes + 64))) return rc;
+    if (!s->ev_copied) KVQ_HIP(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
     KVQ_HIP(hipMemcpyAsync(s->d_stage.p, h_data, (size_t)nbytes, hipMemcpyHostToDevice, s->stream));
+    KVQ_HIP(hipEventRecord(s->ev_copied, s->stream));
     Batch b; b.d_data = nullptr; b.nbytes = nbytes; b.fpos_base = fpos_base;
+    b.chunk_off.assign(chunk_off, chunk_off + nchunks + 1);
     s->batches.push_back(b);
     s->host_batches = true;
     s->parsed += nbytes; s->total += nbytes;
     rc = run_batch(s, s->d_stage.as<uint8_t>(), nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1, false);
-    if (rc || !(s->path_bits & 1)) return rc;
-    // the staging buffer is about to be reused: learn now whether the seed-filter pass of this
-    // batch was validated; if not, scan the batch again exactly while the text is still here
-    unsigned int fail = 0;
-    KVQ_HIP(hipStreamSynchronize(s->stream));
-    KVQ_HIP(hipMemcpy(&fail, s->d_fail + (s->batches.size() - 1), 4, hipMemcpyDeviceToHost));
-    if (!fail) return KVQ_OK;
-    s->batches.back().redone = true;
-    Batch again; again.d_data = nullptr; again.nbytes = nbytes; again.fpos_base = fpos_base; again.redone = true; again.is_redo = true;
-    s->batches.push_back(again);
-    s->path_bits |= 4;
-    return run_batch(s, s->d_stage.as<uint8_t>(), nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1, true);
+    if (rc) return rc;
+    if (s->path_bits & 1)
+        KVQ_HIP(hipMemcpyAsync(s->pin_small + 40, s->d_fail + (s->batches.size() - 1), 4, hipMemcpyDeviceToHost, s->stream));
+    s->host_pending = (int64_t)s->batches.size() - 1;
+    return KVQ_OK;
+}
+
+// wait until the text of the last kvq_scan_host_async batch has left the host buffer
+extern "C" int32_t kvq_scan_host_copied(kvq_scan *s)
+{
+    if (s->ev_copied) KVQ_HIP(hipEventSynchronize(s->ev_copied));
+    return KVQ_OK;
+}
+
+// the blocking form: h_data may be reused when the call returns
+extern "C" int32_t kvq_scan_host(kvq_scan *s, const void *h_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base)
+{
+    const int rc = kvq_scan_host_async(s, h_data, nbytes, chunk_off, nchunks, fpos_base);
+    return rc ? rc : kvq_scan_host_copied(s);
 }
 
 static int finish_once(kvq_scan *s)
 {
     const double t0 = now_ms();
+    { const int rc0 = kvq_scan_host_drain(s); if (rc0) return rc0; }          // settle the host batch in flight
     // the scan's small words (hit count, hit bytes, first error) and the per-batch "speculation
     // failed" flags arrive behind everything that is enqueued: one wait for all of it
     const size_t nb0 = s->batches.size();
