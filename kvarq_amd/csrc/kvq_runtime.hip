@@ -496,6 +496,7 @@ extern "C" int32_t kvq_scan_host_async(kvq_scan *s, const void *h_data, int64_t 
     if (nbytes <= 0) return KVQ_OK;
     int rc = kvq_scan_host_drain(s); if (rc) return rc;          // the staging buffer and the table pool are free again
     s->pool.used = 0;
+    *reinterpret_cast<unsigned int *>(s->pin_small + 40) = 0;    // "speculation failed" of the batch about to be enqueued
     if ((rc = s->d_stage.ensure((size_t)nbytes + 64))) return rc;
     if (!s->ev_copied) KVQ_HIP(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
     KVQ_HIP(hipMemcpyAsync(s->d_stage.p, h_data, (size_t)nbytes, hipMemcpyHostToDevice, s->stream));
