@@ -180,8 +180,28 @@ struct SeededLds {
     uint32_t rinfo[ST_RCAP];             // read offset in buf | rl << 16
     __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];   // newlines per wave: all ...
     __attribute__((aligned(16))) uint32_t wown[ST_WAVES];   // ... and those the tile owns
-    uint32_t longest_p1, records, fallback;
+    uint32_t longest_p1, records, fallback, flip;
 };
+
+// A byte of LDS by its absolute address.  The kernel's only LDS object is the dynamic block, which
+// starts at LDS address 0 (checked at kernel start); spelling the address out saves the
+// "add the base (0)" instruction the compiler otherwise emits for every computed index.
+#define KVQ_LDS_BMA ((uint32_t)offsetof(SeededLds, bmA))
+__device__ __forceinline__ uint32_t lds_byte_at(uint32_t addr)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>((uintptr_t)addr);
+}
+// a dword of buf[] at byte offset off (a multiple of 4) / at any offset (buf is the first member: LDS address = off)
+static_assert(offsetof(SeededLds, buf) == 0, "buf[] first");
+__device__ __forceinline__ uint32_t buf_u32(uint32_t off)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)off);
+}
+__device__ __forceinline__ uint32_t buf_u32_any(uint32_t off)
+{
+    typedef uint32_t __attribute__((aligned(1))) u32_any;
+    return *reinterpret_cast<const __attribute__((address_space(3))) u32_any *>((uintptr_t)off);
+}
 
 // values that are the same in every lane (LDS reads at uniform addresses, wave
 // numbers) must be moved to scalar registers by hand: the compiler cannot know
@@ -222,12 +242,21 @@ __device__ __forceinline__ uint32_t code8x2_of(uint32_t lo, uint32_t hi)
 __device__ __forceinline__ uint32_t lds_code8x2(const SeededLds &S, uint32_t off)
 {
     const uint32_t w = off & ~3u, sh = (off & 3u) * 8u;
-    const uint32_t d0 = *reinterpret_cast<const uint32_t *>(&S.buf[w]), d1 = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u]),
-                   d2 = *reinterpret_cast<const uint32_t *>(&S.buf[w + 8u]);
+    const uint32_t d0 = buf_u32(w), d1 = buf_u32(w + 4u),
+                   d2 = buf_u32(w + 8u);
     return code8x2_of(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh));
 }
 __device__ __forceinline__ uint32_t lds_code8(const SeededLds &S, uint32_t off) { return lds_code8x2(S, off) >> 1; }
-__device__ __forceinline__ uint32_t glb_code8(const uint8_t *x)
+// bytes of the sequence table: a pointer read from memory is "generic" to the compiler, which then
+// uses flat loads that also tie up the LDS counter; these say "global memory"
+typedef const __attribute__((address_space(1))) uint8_t *GlbBytes;
+__device__ __forceinline__ uint32_t glb_u32(GlbBytes p)                         // any alignment
+{
+    typedef uint32_t __attribute__((aligned(1))) u32_any;
+    return *reinterpret_cast<const __attribute__((address_space(1))) u32_any *>(p);
+}
+__device__ __forceinline__ uint32_t glb_code8(GlbBytes x) { return code8x2_of(glb_u32(x), glb_u32(x + 4)) >> 1; }
+__device__ __forceinline__ uint32_t glb_code8(const uint8_t *x)                 // (planes kernel: generic pointers)
 {
     uint32_t lo, hi;
     __builtin_memcpy(&lo, x, 4); __builtin_memcpy(&hi, x + 4, 4);
@@ -282,7 +311,7 @@ __device__ __forceinline__ Seg seg_merge(const Seg &A, const Seg &B)
 }
 
 // is the seed (read block at rp, sequence block at sq) live: equal 2-bit codes
-__device__ __forceinline__ bool seed_live(const SeededLds &S, uint32_t roff, int rl, int rp, const uint8_t *seq, int seql, int sq)
+__device__ __forceinline__ bool seed_live(const SeededLds &S, uint32_t roff, int rl, int rp, GlbBytes seq, int seql, int sq)
 {
     if (rp < 0 || rp + SK > rl || sq < 0 || sq + SK > seql) return false;
     return lds_code8(S, roff + (uint32_t)rp) == glb_code8(seq + sq);
@@ -302,7 +331,7 @@ __device__ __forceinline__ int diff_bytes(uint32_t x, uint32_t y)
 // the device copy where it is needed (hits, errors, the final flush)
 struct HotParams {
     const KvqParams *cold;
-    const uint8_t *tab;
+    GlbBytes tab;
     int maxerrors, minoverlap, minreadlength, amin;
 };
 
@@ -340,7 +369,7 @@ __device__ __forceinline__ void verify_item(const HotParams &P, const SeededLds 
         fpos = tile_fpos + (int64_t)roff - (int64_t)ST_PRE;
         const int q = (int)(en & 4095u);
         s = (int)((en >> 12) & 0xFFFFFu);
-        const uint8_t *seq = P.tab + (uint32_t)((en >> 32) & 0xFFFFFu);
+        const GlbBytes seq = P.tab + (uint32_t)((en >> 32) & 0xFFFFFu);
         const int seql = (int)(en >> 52);
         const int mo = P.minoverlap, me = P.maxerrors;
         const int d = q - p;                             // sequence index = read index + d
@@ -349,12 +378,12 @@ __device__ __forceinline__ void verify_item(const HotParams &P, const SeededLds 
         // most false candidates die here, on the first 16 bytes of the diagonal (one round trip),
         // before anything else is worked out for them
         int mism = 0, j = 0;
-        const uint32_t x = roff + (uint32_t)a; const uint8_t *y = seq + a + d;
+        const uint32_t x = roff + (uint32_t)a; const GlbBytes y = seq + a + d;
         bool alive = L > 0;
         if (alive && L >= 16) {
             uint32_t rw[4], sw[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) { __builtin_memcpy(&rw[t], &S.buf[x + 4 * t], 4); __builtin_memcpy(&sw[t], y + 4 * t, 4); }
+            for (int t = 0; t < 4; t++) { rw[t] = buf_u32_any(x + 4u * (uint32_t)t); sw[t] = glb_u32(y + 4 * t); }
 #pragma unroll
             for (int t = 0; t < 4; t++) mism += diff_bytes(rw[t], sw[t]);
             j = 16;
@@ -379,7 +408,7 @@ __device__ __forceinline__ void verify_item(const HotParams &P, const SeededLds 
         if (canAB || canC) {
             for (; j + 4 <= L && mism <= me; j += 4) {
                 uint32_t rw, sw;
-                __builtin_memcpy(&rw, &S.buf[x + j], 4); __builtin_memcpy(&sw, y + j, 4);
+                rw = buf_u32_any(x + (uint32_t)j); sw = glb_u32(y + j);
                 mism += diff_bytes(rw, sw);
             }
             for (; j < L && mism <= me; j++) mism += (S.buf[x + j] != y[j]);
@@ -438,10 +467,17 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
     SeededLds &S = *reinterpret_cast<SeededLds *>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = rfl((uint32_t)tid >> 6);
+    // A tile's reads fill the workgroup's waves from one end (98 reads of 150 bp: six full waves,
+    // one with two reads, one idle), and the hardware places wave w of every workgroup on SIMD w % 4.
+    // If both workgroups of a CU filled from wave 0, SIMDs 0 and 1 would carry four full instruction
+    // streams and SIMD 3 two.  The workgroup that sits in the upper wave slots fills from wave 7 down.
+    if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t *)lds_raw) != 0u) __builtin_trap();   // lds_byte_at
+    // (wave 0 decides for the workgroup; the fill order must be the same in all of its waves)
+    if (tid == 0) S.flip = (((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) >> 1) & 1u) ^ ((dbg >> 5) & 1u);   // HW_ID.WAVE_ID
     HotParams P;
-    P.cold = Pg; P.tab = Pg->tab; P.maxerrors = Pg->maxerrors; P.minoverlap = Pg->minoverlap;
+    P.cold = Pg; P.tab = (GlbBytes)Pg->tab; P.maxerrors = Pg->maxerrors; P.minoverlap = Pg->minoverlap;
     P.minreadlength = Pg->minreadlength; P.amin = Pg->amin;
-    unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_t = 0;
+    unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_t = 0, wave_p34 = 0;
 #define STAMP(i) do { if constexpr (STAMPS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
 
     for (int i = tid; i < 4096; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = X.bm1[i];     // bmA and bmL are adjacent
@@ -464,6 +500,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? J.load_lo + toff + 16u * r : ~15u, J.load_hi);
     }
     __syncthreads();
+    const uint32_t lwave = rfl(S.flip) ? (uint32_t)(ST_WAVES - 1) - wave : wave;
 
     for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
         const TileGeo J = tile_geo(g, tiles);
@@ -588,6 +625,8 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         }
 
         STAMP(3);
+        unsigned long long wave_t3 = 0;
+        if constexpr (STAMPS) wave_t3 = __builtin_amdgcn_s_memtime();
         // ---- P3 / P4 passes: reads -> candidates, then candidates -> hits ----
         // G lanes share one read (G = 4 for 150 bp reads): each lane scans a contiguous
         // slice of the score line / of the bases serially, so that one wave instruction
@@ -596,7 +635,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         uint32_t lg = 0;
         while (lg < 6u && (2u << lg) * nrec <= (ST_THREADS >> ((dbg >> 8) & 3u))) lg++;     // (dbg bits 8-9: experiment with narrower groups)
         const uint32_t G = 1u << lg, RP = ST_THREADS >> lg;
-        const uint32_t gl = (uint32_t)tid & (G - 1u), gr = (uint32_t)tid >> lg;
+        const uint32_t gl = (uint32_t)tid & (G - 1u), gr = (lwave * 64u + (uint32_t)lane) >> lg;    // reads go to waves in lwave order
         for (uint32_t pass0 = 0; pass0 < nrec; pass0 += RP) {
             const uint32_t k = pass0 + gr;
             const bool have = k < nrec;
@@ -634,7 +673,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                             // slice needs no more), whatever is left in rounds of 16
                             uint32_t q[12];
 #pragma unroll
-                            for (int t = 0; t < 12; t++) q[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
+                            for (int t = 0; t < 12; t++) q[t] = buf_u32(w + 4u * t);
 #pragma unroll
                             for (int u = 0; u < 3; u++) {
                                 const uint32_t g16 = kvq_flags16(good_flags(q[4 * u], addk), good_flags(q[4 * u + 1], addk),
@@ -647,7 +686,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                         for (; w < abs1; w += 16u, sh += 16) {
                             uint32_t q[4];
 #pragma unroll
-                            for (int t = 0; t < 4; t++) q[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
+                            for (int t = 0; t < 4; t++) q[t] = buf_u32(w + 4u * t);
                             const uint32_t g16 = kvq_flags16(good_flags(q[0], addk), good_flags(q[1], addk), good_flags(q[2], addk), good_flags(q[3], addk));
                             m |= sh >= 0 ? ((uint64_t)g16 << sh) : ((uint64_t)g16 >> (-sh));
                         }
@@ -722,7 +761,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
             // Normally one stretch; when a queue overflows (dense tables, hit-rich reads) the
             // stretch is redone in halves
             const uint32_t rpw = 64u >> lg, grw = (uint32_t)lane >> lg;        // reads per wave, this lane's read within the wave
-            const uint32_t wfirst = pass0 + wave * rpw;                        // the wave's first read of this pass
+            const uint32_t wfirst = pass0 + lwave * rpw;                       // the wave's first read of this pass
             const uint32_t npass = wfirst < nrec ? (nrec - wfirst < rpw ? nrec - wfirst : rpw) : 0u;
             uint2 *const q1 = S.q1 + wave * ST_QW; uint32_t *const q2 = S.q2 + wave * ST_Q2W;
             uint32_t sub = 0, step = rpw;
@@ -771,7 +810,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                             const int i = i0 + u * (int)G;
                             const uint32_t w = (roff + 16u * (uint32_t)(i < nw ? i : 0)) & ~3u;
 #pragma unroll
-                            for (int t = 0; t < 5; t++) d[u][t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
+                            for (int t = 0; t < 5; t++) d[u][t] = buf_u32(w + 4u * t);
                         }
 #pragma unroll
                         for (int u = 0; u < 3; u++) {
@@ -791,28 +830,41 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                         const uint32_t src = roff + 8u * (uint32_t)(act ? ee : 0), w = src & ~3u, sh8 = (src & 3u) * 8u;
                         uint32_t D[2 * NR + 1];
 #pragma unroll
-                        for (int t = 0; t < 2 * NR + 1; t++) D[t] = *reinterpret_cast<const uint32_t *>(&S.buf[w + 4u * t]);
+                        for (int t = 0; t < 2 * NR + 1; t++) D[t] = buf_u32(w + 4u * t);
+                        uint32_t c2[NR], bb[NR];
 #pragma unroll
                         for (int j = 0; j < NR; j++) {
-                            const uint32_t c2 = code8x2_of(__builtin_amdgcn_alignbit(D[2 * j + 1], D[2 * j], sh8),
-                                                           __builtin_amdgcn_alignbit(D[2 * j + 2], D[2 * j + 1], sh8));
-                            hA |= (((uint32_t)S.bmA[c2 >> 4] >> ((c2 >> 1) & 7u)) & 1u) << j;
+                            c2[j] = code8x2_of(__builtin_amdgcn_alignbit(D[2 * j + 1], D[2 * j], sh8),
+                                               __builtin_amdgcn_alignbit(D[2 * j + 2], D[2 * j + 1], sh8));
+                            bb[j] = lds_byte_at(KVQ_LDS_BMA + (c2[j] >> 4));
                         }
+                        asm volatile("" ::: "memory");                          // all bitmap bytes are on their way before the first is looked at
+#pragma unroll
+                        for (int j = 0; j < NR; j++) hA |= __builtin_amdgcn_ubfe(bb[j], (c2[j] >> 1) & 7u, 1u) << j;
                     } else {
                         const uint32_t bit = act ? 2u * SS * (uint32_t)ee : 0u;  // packed stream: 2 bits per base
                         const uint32_t wi = bit >> 5, bo = bit & 31u;
                         uint32_t W[5];
 #pragma unroll
-                        for (int t = 0; t < 5; t++) W[t] = *reinterpret_cast<const uint32_t *>(&S.buf[pkb + 4u * (wi + (uint32_t)t)]);
+                        for (int t = 0; t < 5; t++) W[t] = buf_u32(pkb + 4u * (wi + (uint32_t)t));
                         const uint32_t R0 = __builtin_amdgcn_alignbit(W[1], W[0], bo), R1 = __builtin_amdgcn_alignbit(W[2], W[1], bo),
                                        R2 = __builtin_amdgcn_alignbit(W[3], W[2], bo), R3 = __builtin_amdgcn_alignbit(W[4], W[3], bo);
+                        // five instructions and a byte from LDS per lookup: window, byte index, bit index, bit, pile up;
+                        // twelve bitmap bytes travel together (left alone the compiler waits for each)
+                        constexpr int NB = 12;
 #pragma unroll
-                        for (int j = 0; j < NR; j++) {
-                            // five instructions and a byte from LDS per lookup: window, byte index, bit index, bit, pile up
-                            const int b = 2 * SS * j, wj = b >> 5;
-                            const uint32_t lo = wj == 0 ? R0 : wj == 1 ? R1 : R2, hi = wj == 0 ? R1 : wj == 1 ? R2 : R3;
-                            const uint32_t win = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(b & 31));   // the code is its low 16 bits
-                            hA |= (((uint32_t)S.bmA[(win >> 3) & 0x1FFFu] >> (win & 7u)) & 1u) << j;
+                        for (int j0 = 0; j0 < NR; j0 += NB) {
+                            uint32_t win[NB], bb[NB];
+#pragma unroll
+                            for (int u = 0; u < NB; u++) {
+                                const int b = 2 * SS * (j0 + u), wj = b >> 5;
+                                const uint32_t lo = wj == 0 ? R0 : wj == 1 ? R1 : R2, hi = wj == 0 ? R1 : wj == 1 ? R2 : R3;
+                                win[u] = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(b & 31));        // the code is its low 16 bits
+                                bb[u] = lds_byte_at(KVQ_LDS_BMA + ((win[u] >> 3) & 0x1FFFu));
+                            }
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int u = 0; u < NB; u++) hA |= __builtin_amdgcn_ubfe(bb[u], win[u] & 7u, 1u) << (j0 + u);
                         }
                     }
                     const int nv = act ? (e1 - ee < NR ? e1 - ee : NR) : 0;
@@ -895,6 +947,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
             }
             STAMP(6);
         }
+        if constexpr (STAMPS) wave_p34 += __builtin_amdgcn_s_memtime() - wave_t3;
         // everyone is done with the tile's text before the next tile's fill
         __syncthreads();
         STAMP(7);
@@ -902,7 +955,12 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
     }
 
     unsigned long long *const ctr = Pg->ctr;
-    if constexpr (STAMPS) { if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]); }
+    if constexpr (STAMPS) {
+        if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
+        // every wave: cycles from the end of P2 to the end of its own P4 (bins 908 + wave)
+        if (lane == 0) atomicAdd(&ctr[KVQ_CTR_RL_ + 908 + wave], wave_p34);
+        if (lane == 0) atomicAdd(&ctr[KVQ_CTR_RL_ + 916 + ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 7u)], 1ull);   // HW wave slots in use
+    }
     // ---- flush per-workgroup counters ----
     for (int i = tid; i < KVQ_RL_BINS; i += ST_THREADS)
         if (S.hist[i]) atomicAdd(&ctr[KVQ_CTR_RL_ + i], (unsigned long long)S.hist[i]);
