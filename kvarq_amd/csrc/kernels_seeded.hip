@@ -2,22 +2,25 @@
 // the FastQ text does record split, quality trim, read-length histogram and
 // matching (workhorse.c:1010-1175) for every sequence that qualifies for seeding.
 //
-// Persistent workgroups (512 threads) walk 32 KiB tiles of the input:
-//   P0  tile (+4 KiB look-ahead) HBM -> registers -> LDS with 16-byte loads;
-//       newline flags are taken from the registers on the way
+// Persistent workgroups (512 threads, two per CU) walk 32000-byte tiles of the input:
+//   P0  every thread fetches the 80 contiguous bytes it scans (buffer loads, issued one tile
+//       ahead), writes them to LDS and takes the newline flags from the registers
 //   P1  workgroup prefix sum -> sorted newline offsets in LDS
 //   P2  first record of the tile: exact for the first tile of a chunk, otherwise
 //       speculated from the text ("@" line followed two lines later by a "+"
 //       line) and verified after the kernel by kvq_validate_tiles against the
 //       exact count of newlines (four '\n' = one record, workhorse.c:1018-1034);
 //       any disagreement makes the host rescan with the exhaustive kernels
-//   P3  one wave per read: '@'/'+' checks (1037-1048), longest run of scores
-//       >= Amin via __ballot (1055-1068), LDS histogram (394-402); the read is
-//       2-bit packed with two ballots and every position's 8-mer is looked up
-//       in LDS-resident bitmaps; candidate (read, position) pairs go to an LDS queue
-//   P4  all lanes verify queued candidates: seed index -> (sequence, diagonal)
-//       -> byte-exact mismatch count under the class A/B/C rules (1112-1174)
-//       -> hits appended to the global arena (one atomic per wave)
+//   P3  G lanes per read (G = 4 at 150 bp), a wave owns its 64/G reads from here on:
+//       '@'/'+' checks (1037-1048), longest run of scores >= Amin from a SWAR bitmask of
+//       good bytes (1055-1068), LDS histogram (394-402); the read's 8-mers at every
+//       stride-th position are looked up in an LDS bitmap of anchor blocks, its head and
+//       tail blocks in the bitmap of all sequence 8-mers; candidates (read, position) go
+//       to the wave's own LDS queue
+//   P4  the wave verifies its candidates, one (candidate, index entry) pair per lane:
+//       (sequence, diagonal) -> byte-exact mismatch count under the class A/B/C rules
+//       (1112-1174) -> hits appended to the global arena (one atomic per wave)
+//   (one barrier at the end of the tile; DESIGN.md section 4.1 has the details and the measurements)
 //
 // Seeding (pigeonhole, K = 8): an accepted alignment of length L >= (e+1)*K
 // with <= e mismatches has an exact K-mer block.  Alignments that start at the
