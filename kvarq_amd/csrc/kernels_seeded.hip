@@ -183,7 +183,7 @@ struct SeededLds {
     uint32_t rinfo[ST_RCAP];             // read offset in buf | rl << 16
     __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];   // newlines per wave: all ...
     __attribute__((aligned(16))) uint32_t wown[ST_WAVES];   // ... and those the tile owns
-    uint32_t longest_p1, records, fallback, flip;
+    uint32_t longest_p1, records, fallback;
 };
 
 // A byte of LDS by its absolute address.  The kernel's only LDS object is the dynamic block, which
@@ -470,13 +470,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
     SeededLds &S = *reinterpret_cast<SeededLds *>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = rfl((uint32_t)tid >> 6);
-    // A tile's reads fill the workgroup's waves from one end (98 reads of 150 bp: six full waves,
-    // one with two reads, one idle), and the hardware places wave w of every workgroup on SIMD w % 4.
-    // If both workgroups of a CU filled from wave 0, SIMDs 0 and 1 would carry four full instruction
-    // streams and SIMD 3 two.  The workgroup that sits in the upper wave slots fills from wave 7 down.
     if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t *)lds_raw) != 0u) __builtin_trap();   // lds_byte_at
-    // (wave 0 decides for the workgroup; the fill order must be the same in all of its waves)
-    if (tid == 0) S.flip = (((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) >> 1) & 1u) ^ ((dbg >> 5) & 1u);   // HW_ID.WAVE_ID
     HotParams P;
     P.cold = Pg; P.tab = (GlbBytes)Pg->tab; P.maxerrors = Pg->maxerrors; P.minoverlap = Pg->minoverlap;
     P.minreadlength = Pg->minreadlength; P.amin = Pg->amin;
@@ -503,7 +497,6 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? J.load_lo + toff + 16u * r : ~15u, J.load_hi);
     }
     __syncthreads();
-    const uint32_t lwave = rfl(S.flip) ? (uint32_t)(ST_WAVES - 1) - wave : wave;
 
     for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
         const TileGeo J = tile_geo(g, tiles);
@@ -638,7 +631,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         uint32_t lg = 0;
         while (lg < 6u && (2u << lg) * nrec <= (ST_THREADS >> ((dbg >> 8) & 3u))) lg++;     // (dbg bits 8-9: experiment with narrower groups)
         const uint32_t G = 1u << lg, RP = ST_THREADS >> lg;
-        const uint32_t gl = (uint32_t)tid & (G - 1u), gr = (lwave * 64u + (uint32_t)lane) >> lg;    // reads go to waves in lwave order
+        const uint32_t gl = (uint32_t)tid & (G - 1u), gr = (uint32_t)tid >> lg;
         for (uint32_t pass0 = 0; pass0 < nrec; pass0 += RP) {
             const uint32_t k = pass0 + gr;
             const bool have = k < nrec;
@@ -764,7 +757,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
             // Normally one stretch; when a queue overflows (dense tables, hit-rich reads) the
             // stretch is redone in halves
             const uint32_t rpw = 64u >> lg, grw = (uint32_t)lane >> lg;        // reads per wave, this lane's read within the wave
-            const uint32_t wfirst = pass0 + lwave * rpw;                       // the wave's first read of this pass
+            const uint32_t wfirst = pass0 + wave * rpw;                        // the wave's first read of this pass
             const uint32_t npass = wfirst < nrec ? (nrec - wfirst < rpw ? nrec - wfirst : rpw) : 0u;
             uint2 *const q1 = S.q1 + wave * ST_QW; uint32_t *const q2 = S.q2 + wave * ST_Q2W;
             uint32_t sub = 0, step = rpw;
@@ -962,7 +955,6 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
         // every wave: cycles from the end of P2 to the end of its own P4 (bins 908 + wave)
         if (lane == 0) atomicAdd(&ctr[KVQ_CTR_RL_ + 908 + wave], wave_p34);
-        if (lane == 0) atomicAdd(&ctr[KVQ_CTR_RL_ + 916 + ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 7u)], 1ull);   // HW wave slots in use
     }
     // ---- flush per-workgroup counters ----
     for (int i = tid; i < KVQ_RL_BINS; i += ST_THREADS)

@@ -24,4 +24,3 @@ for nm, v in zip(names, c): print('%-16s %6.1f%%  %8.0f cycles/tile' % (nm, 100*
 if os.environ.get('KVQ_KERNEL') != 'planes':
     w = r['counters'][4+908:4+916].astype(np.float64) / (n*rb/tile_bytes)
     print('P3+P4 cycles/tile by wave:', ' '.join('%.0f' % v for v in w))
-    print('waves by HW_ID.WAVE_ID 0..7:', r['counters'][4+916:4+924].tolist())
