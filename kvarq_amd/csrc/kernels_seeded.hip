@@ -35,7 +35,7 @@
 #include <string.h>
 
 #define SK 8                       // seed length
-#define ST_TILE 32000u             // bytes a tile owns: 400 scan blocks of 80 bytes
+#define ST_TILE 36640u             // bytes a tile owns at the full look-ahead: 458 scan blocks of 80 bytes (tile + look-ahead = 510 blocks)
 #define ST_OV 4160u                // look-ahead for the tile's last record (52 blocks)
 #define ST_PRE 80u                 // one (zeroed) block in front of the tile: buf[ST_PRE] = first owned byte
 #define ST_THREADS 512
@@ -43,12 +43,13 @@
 #define ST_ROUNDS ((ST_TILE + ST_OV) / 16u / ST_THREADS + 1)    // 16-byte loads per thread
 #define ST_NLCAP 2048
 #define ST_RCAP 512
-#define ST_QCAP 1024            // candidates (read, position): ST_QW per wave and stretch
+#define ST_QCAP 896             // candidates (read, position): ST_QW per wave and stretch
 #define ST_Q2CAP 2048           // candidate x index entry pairs: ST_Q2W per wave and stretch
 #define ST_QW (ST_QCAP / ST_WAVES)
 #define ST_Q2W (ST_Q2CAP / ST_WAVES)
 #define ST_BLK 80u              // bytes one thread scans for newlines (LDS conflict-free stride)
 #define ST_BUF (ST_PRE + ST_TILE + ST_OV)
+#define ST_HIST_TILES 100u      // x ST_RCAP reads per tile < 65536: the 16-bit histogram bins cannot run over
 
 // tile report word for kvq_validate_tiles
 #define TR_NONE 0xFFu              // no record starts in this tile
@@ -177,7 +178,7 @@ struct SeededLds {
     uint8_t  buf[ST_BUF];                // buf[ST_PRE] = first byte the tile owns
     uint16_t nl[ST_NLCAP];               // offsets into buf of every '\n', ascending
     uint8_t  bmA[8192], bmL[8192];       // one bit per 8-mer code: an anchor block of some sequence / anywhere in some sequence
-    uint32_t hist[KVQ_RL_BINS];
+    uint32_t hist[KVQ_RL_BINS / 2];      // read-length histogram, two 16-bit bins per word, flushed every ST_HIST_TILES tiles
     uint2    q1[ST_QCAP];                // candidate: x = rec | pos << 16, y = code | kind << 16
     uint32_t q2[ST_Q2CAP];               // work item: candidate << 22 | index entry
     uint32_t rinfo[ST_RCAP];             // read offset in buf | rl << 16
@@ -206,6 +207,8 @@ __device__ __forceinline__ uint32_t buf_u32_any(uint32_t off)
     return *reinterpret_cast<const __attribute__((address_space(3))) u32_any *>((uintptr_t)off);
 }
 
+static_assert(sizeof(SeededLds) <= 80 * 1024, "two workgroups per CU: at most 80 KB of LDS each");
+
 // values that are the same in every lane (LDS reads at uniform addresses, wave
 // numbers) must be moved to scalar registers by hand: the compiler cannot know
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -219,14 +222,15 @@ struct TileGeo {
     uint32_t load_lo, load_hi, lds_lo;   // loaded byte range [load_lo, load_hi) lands at buf[lds_lo ...]
 };
 
-__device__ __forceinline__ TileGeo tile_geo(uint32_t g, const uint4 *tiles)
+__device__ __forceinline__ TileGeo tile_geo(uint32_t g, const uint4 *tiles, uint32_t tile_bytes)
 {
     // the per-tile table kvq_expand_tiles wrote: {chunk begin, chunk end, tile number, chunk}
     TileGeo J;
     const uint4 q = tiles[g];
     J.a = q.x; J.b = q.y; J.t = q.z;
-    J.g0 = (J.a & ~15u) + J.t * ST_TILE;
-    J.own_end = J.g0 + ST_TILE < J.b ? J.g0 + ST_TILE : J.b;
+    // a tile owns tile_bytes and looks ST_TILE + ST_OV - tile_bytes ahead (the LDS buffer holds both)
+    J.g0 = (J.a & ~15u) + J.t * tile_bytes;
+    J.own_end = J.g0 + tile_bytes < J.b ? J.g0 + tile_bytes : J.b;
     J.own_begin = J.t == 0 ? J.a : J.g0;
     J.load_lo = J.g0;
     J.load_hi = J.g0 + ST_TILE + ST_OV < J.b ? J.g0 + ST_TILE + ST_OV : J.b;
@@ -459,12 +463,24 @@ __device__ __forceinline__ uint32_t bits8_at(uint32_t w0, uint32_t w1, uint32_t 
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)lane & 31u) & 0xFFu;
 }
 
+// the workgroup's read-length histogram -> global counters (all threads; the caller puts barriers around it)
+__device__ __forceinline__ void flush_hist(SeededLds &S, unsigned long long *ctr, int tid)
+{
+    for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) {
+        const uint32_t w = S.hist[i];
+        if (w & 0xFFFFu) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i], (unsigned long long)(w & 0xFFFFu));
+        if (w >> 16) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i + 1], (unsigned long long)(w >> 16));
+        S.hist[i] = 0;
+    }
+}
+
 // SS = lookup stride of the anchor blocks (SeedTables::stride); STAMPS = diagnostic build that
 // sums wave 0's cycles per phase (KVQ_DBG=16, tools/phase_stamps.py)
 template <int SS, bool STAMPS>
 __global__ void __launch_bounds__(ST_THREADS, 4)
 kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__restrict__ data, int64_t fpos_base,
-                const uint4 *__restrict__ tiles, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg)
+                const uint4 *__restrict__ tiles, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg,
+                uint32_t tile_bytes)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
     SeededLds &S = *reinterpret_cast<SeededLds *>(lds_raw);
@@ -478,7 +494,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
 #define STAMP(i) do { if constexpr (STAMPS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
 
     for (int i = tid; i < 4096; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = X.bm1[i];     // bmA and bmL are adjacent
-    for (int i = tid; i < KVQ_RL_BINS; i += ST_THREADS) S.hist[i] = 0;
+    for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) S.hist[i] = 0;
     if (tid == 0) { S.longest_p1 = 0; S.records = 0; S.fallback = 0; }
     if (tid < (int)(ST_PRE / 4)) reinterpret_cast<uint32_t *>(S.buf)[tid] = 0;      // the block in front of the tile never holds text
 
@@ -492,14 +508,15 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
     const uint32_t blk = (uint32_t)tid * ST_BLK;                           // the block's place in buf
     const uint32_t toff = blk - ST_PRE;                                    // ... and in the tile's text (tid >= 1)
     if (blockIdx.x < ntiles) {
-        const TileGeo J = tile_geo(blockIdx.x, tiles);
+        const TileGeo J = tile_geo(blockIdx.x, tiles, tile_bytes);
 #pragma unroll
         for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? J.load_lo + toff + 16u * r : ~15u, J.load_hi);
     }
     __syncthreads();
 
+    uint32_t tiles_done = 0;
     for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
-        const TileGeo J = tile_geo(g, tiles);
+        const TileGeo J = tile_geo(g, tiles, tile_bytes);
         if constexpr (STAMPS) stamp_t = __builtin_amdgcn_s_memtime();
         // every vector load has to be back here anyway; saying so on all paths keeps the
         // compiler from waiting for the next tile's loads in the middle of this tile
@@ -534,7 +551,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
             fl[4 * r + 2] = kvq_nl_flags(v.z); fl[4 * r + 3] = kvq_nl_flags(v.w);
         }
         if (g + gridDim.x < ntiles) {
-            const TileGeo N = tile_geo(g + gridDim.x, tiles);
+            const TileGeo N = tile_geo(g + gridDim.x, tiles, tile_bytes);
 #pragma unroll
             for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? N.load_lo + toff + 16u * r : ~15u, N.load_hi);
         }
@@ -745,7 +762,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                     roff = sread + (uint32_t)__shfl(sg.bstart, lane & ~(int)(G - 1u), 64);             // 1070
                 }
                 if (gl == 0) {
-                    if (rl < KVQ_RL_BINS) atomicAdd(&S.hist[rl], 1u);                                 // 394-402
+                    if (rl < KVQ_RL_BINS) atomicAdd(&S.hist[rl >> 1], 1u << (16 * (rl & 1)));          // 394-402
                     atomicMax(&S.longest_p1, (uint32_t)(rl + 1));
                     S.rinfo[k] = roff | ((uint32_t)rl << 16);
                 }
@@ -948,6 +965,11 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         __syncthreads();
         STAMP(7);
         if (tid == 0 && S.fallback) { atomicOr(&tile_report[g], TR_FLAG_FALLBACK); S.fallback = 0; }
+        if (++tiles_done == ST_HIST_TILES) {                      // (uniform: every thread counts the same tiles)
+            flush_hist(S, Pg->ctr, tid);
+            tiles_done = 0;
+            __syncthreads();
+        }
     }
 
     unsigned long long *const ctr = Pg->ctr;
@@ -957,8 +979,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         if (lane == 0) atomicAdd(&ctr[KVQ_CTR_RL_ + 908 + wave], wave_p34);
     }
     // ---- flush per-workgroup counters ----
-    for (int i = tid; i < KVQ_RL_BINS; i += ST_THREADS)
-        if (S.hist[i]) atomicAdd(&ctr[KVQ_CTR_RL_ + i], (unsigned long long)S.hist[i]);
+    flush_hist(S, ctr, tid);
     if (tid == 0) {
         if (S.longest_p1) atomicMax(&ctr[KVQ_CTR_LONGEST_], (unsigned long long)S.longest_p1);
         if (S.records) atomicAdd(&ctr[KVQ_CTR_RECORDS_], (unsigned long long)S.records);
@@ -1004,6 +1025,30 @@ kvq_expand_tiles(uint32_t nchunks, const uint32_t *__restrict__ chunk_off, const
     for (uint32_t g = g0; g < tile_first[c + 1]; g++) tile_tab[g] = make_uint4(a, b, g - g0, c);
 }
 
+// Bytes a tile owns (a multiple of ST_BLK, ST_TILE .. ST_TILE + ST_OV - 1040): the LDS buffer holds
+// ST_TILE + ST_OV bytes, and what a tile does not own it reads a second time as the look-ahead for
+// its last record.  The look-ahead must cover the longest record; `maxline` is the longest line
+// (with its newline) among the first bytes of the scan, a record has four lines.  A later record
+// that outgrows the look-ahead sends its batch to the exhaustive kernels (and the scan back to the
+// full look-ahead), so this is a matter of speed only.
+uint32_t kvq_choose_tile(uint32_t maxline)
+{
+    if (const char *e = getenv("KVQ_TILE")) { const int v = atoi(e); if (v >= 4000 && v <= (int)(ST_TILE + ST_OV - 1040u)) return (uint32_t)v / ST_BLK * ST_BLK; }
+    if (maxline == 0) return ST_TILE;
+    uint32_t ov = (4u * (maxline + 2u) + 160u + ST_BLK - 1u) / ST_BLK * ST_BLK;
+    ov = std::max<uint32_t>(1040u, std::min<uint32_t>(ov, ST_OV));
+    return ST_TILE + ST_OV - ov;
+}
+
+// the longest line (newline included) among the first bytes of a text; an unfinished last line counts
+uint32_t kvq_longest_line(const uint8_t *text, size_t n)
+{
+    uint32_t best = 0; size_t start = 0;
+    for (size_t i = 0; i < n; i++)
+        if (text[i] == '\n') { best = std::max<uint32_t>(best, (uint32_t)(i + 1 - start)); start = i + 1; }
+    return std::max<uint32_t>(best, (uint32_t)(n - start));
+}
+
 int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
                       const uint32_t *d_chunk_off, int64_t nchunks, int64_t fpos_base, uint32_t max_chunk_bytes)
 {
@@ -1011,7 +1056,16 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     SeedIndex *ix = s->t->index;
     // tiles per chunk; the tables live in the scan's pool so that nothing here waits for the GPU
     const std::vector<int64_t> &co = s->cur_chunk_off;
-    const uint32_t TILE = ix->variant ? kvq_planes_tile_bytes() : ST_TILE;
+    if (!ix->variant && s->tile_bytes == 0) {
+        // first batch of a device-resident scan: look at the head of the text once (the choice is kept
+        // across kvq_scan_reset; host batches are sized on the host, kvq_scan_host_async)
+        const size_t n = (size_t)std::min<int64_t>(nbytes, 128 << 10);
+        std::vector<uint8_t> head(n);
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        KVQ_HIP(hipMemcpy(head.data(), d_data, n, hipMemcpyDeviceToHost));
+        s->tile_bytes = kvq_choose_tile(kvq_longest_line(head.data(), n));
+    }
+    const uint32_t TILE = ix->variant ? kvq_planes_tile_bytes() : s->tile_bytes;
     uint64_t nt = 0;
     for (int64_t c = 0; c < nchunks; c++) {
         const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
@@ -1040,7 +1094,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     KVQ_HIP(hipMemcpyAsync(d_first, first, first_b + sizeof(KvqParams), hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
 
-    typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t);
+    typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t);
     static const SeededKernel kernels[6] = { kvq_scan_seeded<2, false>, kvq_scan_seeded<4, false>, kvq_scan_seeded<8, false>,
                                              kvq_scan_seeded<2, true>, kvq_scan_seeded<4, true>, kvq_scan_seeded<8, true> };
     static bool attr_set = false;
@@ -1060,7 +1114,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, grid_cap);
         const SeededKernel kern = kernels[(ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0) + ((dbg & 16u) ? 3 : 0)];
         hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), sizeof(SeededLds), s->stream, d_params, ix->dev, d_data, fpos_base,
-                           reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg);
+                           reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg, TILE);
     }
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                        d_first, d_report, s->cur_fail);

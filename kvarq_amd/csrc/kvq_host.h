@@ -79,6 +79,7 @@ struct kvq_scan {
     DevBuf d_chunk_off, d_seg_base, d_seg_cnt, d_chunk_nrec, d_rec_base, d_nl4, d_rec_start, d_read_off, d_read_len;
     // hit arena
     DevBuf d_covdiff;                  // coverage marks (KvqParams::covdiff)
+    uint32_t tile_bytes = 0;           // bytes a tile of the seed-filter kernel owns (0 = not chosen yet; kvq_choose_tile)
     DevBuf d_arena, d_blob, d_small;   // d_small: arena_n, batch range words, blob_n, err
     uint32_t arena_cap = 0; uint64_t blob_cap = 0;
     unsigned int *d_arena_n = nullptr, *d_range = nullptr, *d_fail = nullptr, *cur_fail = nullptr;
@@ -114,6 +115,9 @@ void       kvq_seed_index_destroy(SeedIndex *ix);
 // enqueue the fused seed-filter scan of one batch; returns KVQ_OK or error
 int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
                       const uint32_t *d_chunk_off, int64_t nchunks, int64_t fpos_base, uint32_t max_chunk_bytes);
+
+uint32_t kvq_choose_tile(uint32_t maxline);
+uint32_t kvq_longest_line(const uint8_t *text, size_t n);
 
 // synth.hip
 // (C ABI only)

@@ -478,6 +478,7 @@ extern "C" int32_t kvq_scan_host_drain(kvq_scan *s)
     const unsigned int fail = *reinterpret_cast<const unsigned int *>(s->pin_small + 40);     // copied behind the batch
     if (!fail) return KVQ_OK;
     s->batches[b].redone = true;
+    s->tile_bytes = kvq_choose_tile(1u << 20);  // (a record may have outgrown the look-ahead: back to the full one)
     Batch again = s->batches[b]; again.is_redo = true;
     s->batches.push_back(again);
     s->path_bits |= 4;
@@ -497,6 +498,8 @@ extern "C" int32_t kvq_scan_host_async(kvq_scan *s, const void *h_data, int64_t 
     int rc = kvq_scan_host_drain(s); if (rc) return rc;          // the staging buffer and the table pool are free again
     s->pool.used = 0;
     *reinterpret_cast<unsigned int *>(s->pin_small + 40) = 0;    // "speculation failed" of the batch about to be enqueued
+    if (s->tile_bytes == 0)                                      // size the seed-filter tiles from the head of the text
+        s->tile_bytes = kvq_choose_tile(kvq_longest_line((const uint8_t *)h_data, (size_t)std::min<int64_t>(nbytes, 128 << 10)));
     if ((rc = s->d_stage.ensure((size_t)nbytes + 64))) return rc;
     if (!s->ev_copied) KVQ_HIP(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
     KVQ_HIP(hipMemcpyAsync(s->d_stage.p, h_data, (size_t)nbytes, hipMemcpyHostToDevice, s->stream));
@@ -554,6 +557,7 @@ static int finish_once(kvq_scan *s)
         for (size_t b = 0; b < nb0; b++) {
             if (!fail[b] || s->batches[b].redone || !s->batches[b].d_data) continue;
             s->batches[b].redone = true;
+            s->tile_bytes = kvq_choose_tile(1u << 20);   // (a record may have outgrown the look-ahead: back to the full one)
             Batch again = s->batches[b]; again.is_redo = true;
             s->batches.push_back(again);
             s->path_bits |= 4; any = true;

@@ -203,11 +203,23 @@ def test_seeded_and_exhaustive_kernels_agree_and_paths_are_as_expected(tmp_path)
         'ragged_crlf': dict(seeded=False, exhaustive=True, rescanned=False),    # e=3, minoverlap 12: not seedable
         'findseqs': dict(seeded=False, exhaustive=True, rescanned=False),
     }
-    want_path['long_reads_x12'] = dict(seeded=True, exhaustive=True, rescanned=True)    # 6 kB records straddle the tile look-ahead: that batch is redone exhaustively
+    # a 9 kB record that starts 36 kB into the text outgrows the look-ahead of the tile that owns it
+    # (a tile and its look-ahead span 40.8 kB): that batch is redone exhaustively
+    want_path['long_reads_straddle'] = dict(seeded=True, exhaustive=True, rescanned=True)
     for name, wp in want_path.items():
-        case = cases.by_name()[name.replace('_x12', '')]
+        case = cases.by_name()[name.replace('_straddle', '')]
         files = case.materialize(tmp_path)
-        data = np.frombuffer(b''.join(open(f, 'rb').read() for f in files[:1]) * (12 if name.endswith('_x12') else 1), dtype=np.uint8)
+        text = b''.join(open(f, 'rb').read() for f in files[:1])
+        if name.endswith('_straddle'):
+            import random
+            rng = random.Random(5)
+            filler = b''
+            while len(filler) < 36000 - 400:
+                b = cases.randseq(rng, 150)
+                filler += cases.rec('f%d' % len(filler), b, 'I' * 150)
+            big = cases.randseq(rng, 4400)
+            text = filler + cases.rec('big', big, 'I' * 4400) + text
+        data = np.frombuffer(text, dtype=np.uint8)
         t = scan.Table(case.seq_bytes(), **case.config)
         res = []
         for force in (False, True):
