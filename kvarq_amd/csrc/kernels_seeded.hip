@@ -580,15 +580,21 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
 #pragma unroll
             for (int w = 0; w < ST_WAVES; w++) { if (w == (int)wave) mine = n_all; n_all += tot[w]; n_own_all += own[w]; }
             uint32_t n = mine + incl - cnt;
-            if (cnt) {
-#pragma unroll
-                for (int v = 0; v < (int)(ST_BLK / 16); v++) {
-                    // 16 flag bits of this vector, then its (few) set bits
-                    uint32_t m16 = kvq_flags16(fl[4 * v], fl[4 * v + 1], fl[4 * v + 2], fl[4 * v + 3]);
-                    while (m16) {
-                        const int bit = __ffs((int)m16) - 1; m16 &= m16 - 1u;
-                        if (n < ST_NLCAP) S.nl[n] = (uint16_t)(blk + 16u * v + (uint32_t)bit);
+            if (__any(cnt != 0u)) {
+                // the block's 80 flag bits in three words, then one loop over its (few) set bits
+                static_assert(ST_BLK == 80u, "five vectors per block");
+                uint32_t m0 = kvq_flags16(fl[0], fl[1], fl[2], fl[3]) | (kvq_flags16(fl[4], fl[5], fl[6], fl[7]) << 16);
+                uint32_t m1 = kvq_flags16(fl[8], fl[9], fl[10], fl[11]) | (kvq_flags16(fl[12], fl[13], fl[14], fl[15]) << 16);
+                uint32_t m2 = kvq_flags16(fl[16], fl[17], fl[18], fl[19]);
+                while (__any((m0 | m1 | m2) != 0u)) {
+                    const bool in0 = m0 != 0u, in1 = m1 != 0u;
+                    const uint32_t w = in0 ? m0 : in1 ? m1 : m2;
+                    if (w) {
+                        const uint32_t pos = blk + (in0 ? 0u : in1 ? 32u : 64u) + (uint32_t)(__ffs((int)w) - 1);
+                        if (n < ST_NLCAP) S.nl[n] = (uint16_t)pos;
                         n++;
+                        const uint32_t w1 = w & (w - 1u);
+                        if (in0) m0 = w1; else if (in1) m1 = w1; else m2 = w1;
                     }
                 }
             }
