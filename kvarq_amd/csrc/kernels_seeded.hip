@@ -175,7 +175,7 @@ void kvq_seed_index_destroy(SeedIndex *ix)
 // ---------------------------------------------------------------------------
 
 struct SeededLds {
-    uint8_t  buf[ST_BUF];                // buf[ST_PRE] = first byte the tile owns
+    uint8_t  buf[ST_BUF + ST_BLK];       // buf[ST_PRE] = first byte the tile owns; one block of slack behind the look-ahead
     uint16_t nl[ST_NLCAP];               // offsets into buf of every '\n', ascending
     uint8_t  bmA[8192], bmL[8192];       // one bit per 8-mer code: an anchor block of some sequence / anywhere in some sequence
     uint32_t hist[KVQ_RL_BINS / 2];      // read-length histogram, two 16-bit bins per word, flushed every ST_HIST_TILES tiles
@@ -530,6 +530,21 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         const uint32_t own_end_l = J.own_end - J.g0 + ST_PRE;              // ownership ends here
         const uint32_t end_l = J.load_hi - J.g0 + ST_PRE;                  // end of the loaded text
         uint32_t fl[ST_BLK / 4]; uint32_t cnt = 0;
+        // only the block with the chunk's first byte (when that is not 16-byte aligned) and the block with
+        // its last byte need masks; a wave without such a block stores and flags its vectors as they
+        // came (thread 0 and the threads behind the text hold zeros, which land in the empty block
+        // in front of the tile and in the slack behind it)
+        const uint32_t blk_lo = J.g0 + toff;
+        const bool edge = tid && (blk_lo < J.own_begin || (blk_lo < J.load_hi && J.load_hi < blk_lo + ST_BLK && (J.load_hi & 15u)));
+        if (!__any(edge)) {
+#pragma unroll
+            for (int r = 0; r < (int)ST_ROUNDS; r++) {
+                const uint4 v = pre[r];
+                *reinterpret_cast<uint4 *>(&S.buf[blk + 16u * r]) = v;
+                fl[4 * r + 0] = kvq_nl_flags(v.x); fl[4 * r + 1] = kvq_nl_flags(v.y);
+                fl[4 * r + 2] = kvq_nl_flags(v.z); fl[4 * r + 3] = kvq_nl_flags(v.w);
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < (int)ST_ROUNDS; r++) {
             const uint32_t off = toff + 16u * r;                                  // relative to g0
