@@ -666,8 +666,11 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         // slice of the score line / of the bases serially, so that one wave instruction
         // advances 64/G reads and hardly anything runs on the scalar unit
         const int64_t tile_fpos = fpos_base + (int64_t)J.g0;
-        uint32_t lg = 0;
-        while (lg < 6u && (2u << lg) * nrec <= (ST_THREADS >> ((dbg >> 8) & 3u))) lg++;     // (dbg bits 8-9: experiment with narrower groups)
+        // the widest group (a power of two, at most 64 lanes) that still gives every read of the
+        // tile its own lanes in one pass: G * nrec <= 512, i.e. lg = 9 - ceil(log2(nrec))
+        static_assert(ST_THREADS == 512, "lg = 9 - ceil(log2(nrec))");
+        const int lg_ = 9 - (nrec > 1u ? 32 - __builtin_clz(nrec - 1u) : 0);
+        const uint32_t lg = lg_ < 0 ? 0u : lg_ > 6 ? 6u : (uint32_t)lg_;
         const uint32_t G = 1u << lg, RP = ST_THREADS >> lg;
         const uint32_t gl = (uint32_t)tid & (G - 1u), gr = (uint32_t)tid >> lg;
         for (uint32_t pass0 = 0; pass0 < nrec; pass0 += RP) {
@@ -693,13 +696,14 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 sg.len = 0; sg.pre = 0; sg.suf = 0; sg.best = 0; sg.bstart = sg.beg;
                 {
                     const uint32_t addk = (uint32_t)(0x80 - P.amin) * 0x01010101u;
-                    for (int c0 = sg.beg; c0 < s1; c0 += 64) {             // one round unless a slice exceeds 64 bytes
+                    // one round of at most 64 score bytes; `more`: the slice may need more than the first twelve dwords
+                    auto round = [&](int c0, bool more) -> Seg {
                         const int n = s1 - c0 < 64 ? s1 - c0 : 64;
                         const uint32_t abs0 = sscore + (uint32_t)c0, abs1 = abs0 + (uint32_t)n;
                         uint32_t w = abs0 & ~3u;
                         const int lead = (int)(abs0 - w);                  // bytes of the first dword in front of the slice
-                        // dwords w, w+4, ... cover the slice; they are fetched four at a time (bytes
-                        // behind the slice are masked off below, the buffer has slack behind its end)
+                        // dwords w, w+4, ... cover the slice (bytes behind the slice are masked off below,
+                        // the buffer has slack behind its end)
                         uint64_t m = 0;
                         int sh = -lead;
                         {
@@ -717,6 +721,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                             }
                             w += 48u; sh += 48;
                         }
+                        if (more)
                         for (; w < abs1; w += 16u, sh += 16) {
                             uint32_t q[4];
 #pragma unroll
@@ -750,7 +755,16 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                             longest_run64(m, n, bl, bs);
                         }
                         sub.best = bl; sub.bstart = c0 + bs;
-                        sg = (c0 == sg.beg) ? sub : seg_merge(sg, sub);
+                        return sub;
+                    };
+                    if (!__any(per > 45)) {
+                        // the usual case: every lane's slice fits the first twelve dwords (45 bytes at any alignment)
+                        sg = round(sg.beg, false);
+                    } else {
+                        for (int c0 = sg.beg; c0 < s1; c0 += 64) {         // one round per 64 bytes of the slice
+                            const Seg sub = round(c0, true);
+                            sg = (c0 == sg.beg) ? sub : seg_merge(sg, sub);
+                        }
                     }
                 }
                 // ordered tree merge over the G lanes of the read
