@@ -182,9 +182,8 @@ struct SeededLds {
     uint2    q1[ST_QCAP];                // candidate: x = rec | pos << 16, y = code | kind << 16
     uint32_t q2[ST_Q2CAP];               // work item: candidate << 22 | index entry
     uint32_t rinfo[ST_RCAP];             // read offset in buf | rl << 16
-    __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];   // newlines per wave: all ...
-    __attribute__((aligned(16))) uint32_t wown[ST_WAVES];   // ... and those the tile owns
-    uint32_t longest_p1, records, fallback;
+    __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];   // newlines per wave
+    uint32_t longest_p1, records, fallback, n_owned;
 };
 
 // A byte of LDS by its absolute address.  The kernel's only LDS object is the dynamic block, which
@@ -570,37 +569,34 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
 #pragma unroll
             for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? N.load_lo + toff + 16u * r : ~15u, N.load_hi);
         }
-#pragma unroll
-        for (int d = 0; d < (int)(ST_BLK / 4); d++) cnt += __popc(fl[d]);
-        const uint32_t cnt_owned = blk < own_end_l ? cnt : 0u;            // own_end_l is a block boundary or the end of the text
+        // the block's 80 flag bits in three words (all that crosses the barrier)
+        static_assert(ST_BLK == 80u, "five vectors per block");
+        uint32_t m0 = kvq_flags16(fl[0], fl[1], fl[2], fl[3]) | (kvq_flags16(fl[4], fl[5], fl[6], fl[7]) << 16);
+        uint32_t m1 = kvq_flags16(fl[8], fl[9], fl[10], fl[11]) | (kvq_flags16(fl[12], fl[13], fl[14], fl[15]) << 16);
+        uint32_t m2 = kvq_flags16(fl[16], fl[17], fl[18], fl[19]);
+        cnt = (uint32_t)(__popc(m0) + __popc(m1) + __popc(m2));
         const uint32_t incl = kvq_wave_incl_scan(cnt);
-        {
-            const uint32_t o = kvq_wave_incl_scan(cnt_owned);
-            if (lane == 63) { S.wtot[wave] = incl; S.wown[wave] = o; }
-        }
+        if (lane == 63) S.wtot[wave] = incl;
         STAMP(0);
         __syncthreads();
         STAMP(1);
-        uint32_t n_all = 0, n_own_all = 0;
+        uint32_t n_all = 0;
         {
             uint32_t mine = 0;
-            uint32_t tot[ST_WAVES], own[ST_WAVES];
+            uint32_t tot[ST_WAVES];
             {
-                // four 16-byte LDS reads instead of sixteen dword reads
+                // two 16-byte LDS reads instead of eight dword reads
                 const uint4 a0 = reinterpret_cast<const uint4 *>(S.wtot)[0], a1 = reinterpret_cast<const uint4 *>(S.wtot)[1];
-                const uint4 b0 = reinterpret_cast<const uint4 *>(S.wown)[0], b1 = reinterpret_cast<const uint4 *>(S.wown)[1];
                 tot[0] = a0.x; tot[1] = a0.y; tot[2] = a0.z; tot[3] = a0.w; tot[4] = a1.x; tot[5] = a1.y; tot[6] = a1.z; tot[7] = a1.w;
-                own[0] = b0.x; own[1] = b0.y; own[2] = b0.z; own[3] = b0.w; own[4] = b1.x; own[5] = b1.y; own[6] = b1.z; own[7] = b1.w;
             }
 #pragma unroll
-            for (int w = 0; w < ST_WAVES; w++) { if (w == (int)wave) mine = n_all; n_all += tot[w]; n_own_all += own[w]; }
+            for (int w = 0; w < ST_WAVES; w++) { if (w == (int)wave) mine = n_all; n_all += tot[w]; }
             uint32_t n = mine + incl - cnt;
+            // newlines the tile owns = those up to the end of its last owned block (own_end_l is a block
+            // boundary or the end of the text): the thread of that block knows the count
+            if (blk < own_end_l && blk + ST_BLK >= own_end_l) S.n_owned = n + cnt;
             if (__any(cnt != 0u)) {
-                // the block's 80 flag bits in three words, then one loop over its (few) set bits
-                static_assert(ST_BLK == 80u, "five vectors per block");
-                uint32_t m0 = kvq_flags16(fl[0], fl[1], fl[2], fl[3]) | (kvq_flags16(fl[4], fl[5], fl[6], fl[7]) << 16);
-                uint32_t m1 = kvq_flags16(fl[8], fl[9], fl[10], fl[11]) | (kvq_flags16(fl[12], fl[13], fl[14], fl[15]) << 16);
-                uint32_t m2 = kvq_flags16(fl[16], fl[17], fl[18], fl[19]);
+                // one loop over the block's (few) set bits
                 while (__any((m0 | m1 | m2) != 0u)) {
                     const bool in0 = m0 != 0u, in1 = m1 != 0u;
                     const uint32_t w = in0 ? m0 : in1 ? m1 : m2;
@@ -622,7 +618,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         uint32_t nrec = 0, jn = TR_NONE;
         {
             const uint32_t n_nl = n_all < ST_NLCAP ? n_all : ST_NLCAP;
-            const uint32_t n_owned = rfl(n_own_all);
+            const uint32_t n_owned = rfl(S.n_owned);
             uint32_t fallback = n_all > ST_NLCAP ? 1u : 0u;
             // a record belongs to the tile that owns the '\n' in front of it (the chunk's
             // first record to tile 0), also when its first byte is the next tile's first
