@@ -218,7 +218,7 @@ struct TileGeo {
     uint32_t g0;            // batch offset of buf[ST_PRE]
     uint32_t own_begin;     // first byte whose newlines this tile counts
     uint32_t own_end;       // batch offset where ownership ends
-    uint32_t load_lo, load_hi, lds_lo;   // loaded byte range [load_lo, load_hi) lands at buf[lds_lo ...]
+    uint32_t load_lo, load_hi;   // loaded byte range [load_lo, load_hi) lands at buf[ST_PRE ...]
 };
 
 __device__ __forceinline__ TileGeo tile_geo(uint32_t g, const uint4 *tiles, uint32_t tile_bytes)
@@ -233,7 +233,6 @@ __device__ __forceinline__ TileGeo tile_geo(uint32_t g, const uint4 *tiles, uint
     J.own_begin = J.t == 0 ? J.a : J.g0;
     J.load_lo = J.g0;
     J.load_hi = J.g0 + ST_TILE + ST_OV < J.b ? J.g0 + ST_TILE + ST_OV : J.b;
-    J.lds_lo = ST_PRE;
     return J;
 }
 
@@ -455,12 +454,6 @@ __device__ __forceinline__ uint4 text_load16(const uint8_t *data, uint32_t gp, u
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-__device__ __forceinline__ uint32_t bits8_at(uint32_t w0, uint32_t w1, uint32_t w2, int lane)
-{
-    // bits lane .. lane+7 of the 96-bit string w0 | w1 << 32 | w2 << 64
-    const uint32_t lo = lane < 32 ? w0 : w1, hi = lane < 32 ? w1 : w2;
-    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)lane & 31u) & 0xFFu;
-}
 
 // the workgroup's read-length histogram -> global counters (all threads; the caller puts barriers around it)
 __device__ __forceinline__ void flush_hist(SeededLds &S, unsigned long long *ctr, int tid)
