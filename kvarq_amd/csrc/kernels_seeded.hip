@@ -479,6 +479,11 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = rfl((uint32_t)tid >> 6);
     if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t *)lds_raw) != 0u) __builtin_trap();   // lds_byte_at
+    // the issue arbiter prefers the older wave of a SIMD, so waves 4..7 (the second wave of the
+    // workgroup on each SIMD) used to reach the tile-end barrier ~2 k cycles behind waves 0..3, which
+    // then waited there; a higher priority for the younger four during the trim evens the arrival
+    // out (during all of P3/P4 it overshoots).  KVQ_DBG bit 6 switches it off.
+    const bool younger = wave >= 4u && ((dbg >> 6) & 1u) == 0u;
     HotParams P;
     P.cold = Pg; P.tab = (GlbBytes)Pg->tab; P.maxerrors = Pg->maxerrors; P.minoverlap = Pg->minoverlap;
     P.minreadlength = Pg->minreadlength; P.amin = Pg->amin;
@@ -648,6 +653,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         }
 
         STAMP(3);
+        if (younger) __builtin_amdgcn_s_setprio(2);
         unsigned long long wave_t3 = 0;
         if constexpr (STAMPS) wave_t3 = __builtin_amdgcn_s_memtime();
         // ---- P3 / P4 passes: reads -> candidates, then candidates -> hits ----
@@ -792,6 +798,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 }
             }
             STAMP(4);
+            if (younger) __builtin_amdgcn_s_setprio(0);
             // filter + verify, wave by wave: a wave's reads (64/G of them), its candidates and its work
             // items are its own (queue segments wave * ST_QW / wave * ST_Q2W, counts in scalar
             // registers), so nothing between here and the end of the tile waits for another wave.
