@@ -183,7 +183,7 @@ struct SeededLds {
     uint32_t q2[ST_Q2CAP];               // work item: candidate << 22 | index entry
     uint32_t rinfo[ST_RCAP];             // read offset in buf | rl << 16
     __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];   // newlines per wave
-    uint32_t longest_p1, records, fallback, n_owned;
+    uint32_t longest_p1, records, fallback, n_owned, next_tile;
 };
 
 // A byte of LDS by its absolute address.  The kernel's only LDS object is the dynamic block, which
@@ -472,7 +472,7 @@ template <int SS, bool STAMPS>
 __global__ void __launch_bounds__(ST_THREADS, 4)
 kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__restrict__ data, int64_t fpos_base,
                 const uint4 *__restrict__ tiles, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg,
-                uint32_t tile_bytes)
+                uint32_t tile_bytes, unsigned int *__restrict__ tile_ctr)
 {
     extern __shared__ __align__(16) uint8_t lds_raw[];
     SeededLds &S = *reinterpret_cast<SeededLds *>(lds_raw);
@@ -509,10 +509,17 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
 #pragma unroll
         for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? J.load_lo + toff + 16u * r : ~15u, J.load_hi);
     }
+    // Tiles are handed out by a counter (*tile_ctr starts at gridDim.x: tiles 0 .. gridDim.x - 1 are the
+    // workgroups' first ones): the two workgroups of a CU do not run at the same pace (the older one wins
+    // the issue arbitration), and with a fixed share the slower ones would finish the launch alone.
+    // A workgroup always knows its next tile (gn, whose text it fetches one tile ahead); thread 0
+    // draws the one after that early in the tile and posts it in LDS before the tile-end barrier.
+    if (tid == 0) S.next_tile = atomicAdd(tile_ctr, 1u);
     __syncthreads();
 
     uint32_t tiles_done = 0;
-    for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
+    uint32_t gn = rfl(S.next_tile);
+    for (uint32_t g = blockIdx.x; g < ntiles; ) {
         const TileGeo J = tile_geo(g, tiles, tile_bytes);
         if constexpr (STAMPS) stamp_t = __builtin_amdgcn_s_memtime();
         // every vector load has to be back here anyway; saying so on all paths keeps the
@@ -562,8 +569,10 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
             fl[4 * r + 0] = kvq_nl_flags(v.x); fl[4 * r + 1] = kvq_nl_flags(v.y);
             fl[4 * r + 2] = kvq_nl_flags(v.z); fl[4 * r + 3] = kvq_nl_flags(v.w);
         }
-        if (g + gridDim.x < ntiles) {
-            const TileGeo N = tile_geo(g + gridDim.x, tiles, tile_bytes);
+        uint32_t drawn = 0;
+        if (tid == 0) drawn = atomicAdd(tile_ctr, 1u);            // the tile after next; the answer is needed at the end of this tile
+        if (gn < ntiles) {
+            const TileGeo N = tile_geo(gn, tiles, tile_bytes);
 #pragma unroll
             for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? N.load_lo + toff + 16u * r : ~15u, N.load_hi);
         }
@@ -993,9 +1002,11 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         }
         if constexpr (STAMPS) wave_p34 += __builtin_amdgcn_s_memtime() - wave_t3;
         // everyone is done with the tile's text before the next tile's fill
+        if (tid == 0) S.next_tile = drawn;
         __syncthreads();
         STAMP(7);
         if (tid == 0 && S.fallback) { atomicOr(&tile_report[g], TR_FLAG_FALLBACK); S.fallback = 0; }
+        g = gn; gn = rfl(S.next_tile);
         if (++tiles_done == ST_HIST_TILES) {                      // (uniform: every thread counts the same tiles)
             flush_hist(S, Pg->ctr, tid);
             tiles_done = 0;
@@ -1104,10 +1115,11 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     }
     if (nt == 0) return KVQ_OK;
     int rc;
+    static const uint32_t grid_cap = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 512);   // two workgroups per CU
     if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 8192, s->stream))) return rc;
     // first tile of every chunk, then the parameter block: one copy
     const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
-    const size_t first_at = s->pool.take(first_b + sizeof(KvqParams));
+    const size_t first_at = s->pool.take(first_b + sizeof(KvqParams) + 16);      // ... and the tile counter behind it
     const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 4);
     uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
     uint64_t acc = 0;
@@ -1118,14 +1130,17 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     }
     first[nchunks] = (uint32_t)acc;
     memcpy(s->pool.h + first_at + first_b, &P, sizeof(KvqParams));
+    const uint32_t grid_seeded = (uint32_t)std::min<uint64_t>(nt, grid_cap);
+    memcpy(s->pool.h + first_at + first_b + sizeof(KvqParams), &grid_seeded, 4);           // tiles below this number are the workgroups' first
     uint32_t *d_first = reinterpret_cast<uint32_t *>(s->pool.d + first_at);
     const KvqParams *d_params = reinterpret_cast<const KvqParams *>(s->pool.d + first_at + first_b);
     uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
     uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
-    KVQ_HIP(hipMemcpyAsync(d_first, first, first_b + sizeof(KvqParams), hipMemcpyHostToDevice, s->stream));
+    KVQ_HIP(hipMemcpyAsync(d_first, first, first_b + sizeof(KvqParams) + 16, hipMemcpyHostToDevice, s->stream));
+    unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + first_at + first_b + sizeof(KvqParams));
     hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
 
-    typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t);
+    typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t, unsigned int *);
     static const SeededKernel kernels[6] = { kvq_scan_seeded<2, false>, kvq_scan_seeded<4, false>, kvq_scan_seeded<8, false>,
                                              kvq_scan_seeded<2, true>, kvq_scan_seeded<4, true>, kvq_scan_seeded<8, true> };
     static bool attr_set = false;
@@ -1141,11 +1156,10 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         hipLaunchKernelGGL(kvq_scan_planes, dim3(grid), dim3(512), kvq_planes_lds_bytes(), s->stream, P, ix->dev, d_data, fpos_base,
                            d_chunk_off, d_tchunk, d_first, (uint32_t)nt, d_report, dbg);
     } else {
-        static const uint32_t grid_cap = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 512);   // two workgroups per CU
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, grid_cap);
+        const uint32_t grid = grid_seeded;
         const SeededKernel kern = kernels[(ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0) + ((dbg & 16u) ? 3 : 0)];
         hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), sizeof(SeededLds), s->stream, d_params, ix->dev, d_data, fpos_base,
-                           reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg, TILE);
+                           reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg, TILE, d_tile_ctr);
     }
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                        d_first, d_report, s->cur_fail);
