@@ -569,8 +569,6 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
             fl[4 * r + 0] = kvq_nl_flags(v.x); fl[4 * r + 1] = kvq_nl_flags(v.y);
             fl[4 * r + 2] = kvq_nl_flags(v.z); fl[4 * r + 3] = kvq_nl_flags(v.w);
         }
-        uint32_t drawn = 0;
-        if (tid == 0) drawn = atomicAdd(tile_ctr, 1u);            // the tile after next; the answer is needed at the end of this tile
         if (gn < ntiles) {
             const TileGeo N = tile_geo(gn, tiles, tile_bytes);
 #pragma unroll
@@ -620,6 +618,11 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         n_all = rfl(n_all);
         __syncthreads();
         STAMP(2);
+        // the tile after next: drawn here, behind the last barrier before the long barrier-free stretch
+        // (a barrier waits for outstanding atomics), wanted at the end of this tile
+        // (by the last wave, which holds the fewest reads: the compiler waits for the answer on the spot)
+        uint32_t drawn = 0;
+        if (tid == ST_THREADS - 64) drawn = atomicAdd(tile_ctr, 1u);
 
         // ---- P2 (every wave, redundantly): which records does this tile own? ----
         uint32_t nrec = 0, jn = TR_NONE;
@@ -1002,7 +1005,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         }
         if constexpr (STAMPS) wave_p34 += __builtin_amdgcn_s_memtime() - wave_t3;
         // everyone is done with the tile's text before the next tile's fill
-        if (tid == 0) S.next_tile = drawn;
+        if (tid == ST_THREADS - 64) S.next_tile = drawn;
         __syncthreads();
         STAMP(7);
         if (tid == 0 && S.fallback) { atomicOr(&tile_report[g], TR_FLAG_FALLBACK); S.fallback = 0; }
