@@ -1117,9 +1117,10 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         nt += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
     }
     if (nt == 0) return KVQ_OK;
-    int rc;
     static const uint32_t grid_cap = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 512);   // two workgroups per CU
-    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 8192, s->stream))) return rc;
+    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 8192 > s->pool.cap) {       // run_batch made the room
+        kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;
+    }
     // first tile of every chunk, then the parameter block: one copy
     const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
     const size_t first_at = s->pool.take(first_b + sizeof(KvqParams) + 16);      // ... and the tile counter behind it
@@ -1139,7 +1140,9 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     const KvqParams *d_params = reinterpret_cast<const KvqParams *>(s->pool.d + first_at + first_b);
     uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
     uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
-    KVQ_HIP(hipMemcpyAsync(d_first, first, first_b + sizeof(KvqParams) + 16, hipMemcpyHostToDevice, s->stream));
+    // chunk offsets (run_batch put them right in front), first tiles, parameters, tile counter: one transfer
+    KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, first_at + first_b + sizeof(KvqParams) + 16 - s->cur_co_at,
+                           hipMemcpyHostToDevice, s->stream));
     unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + first_at + first_b + sizeof(KvqParams));
     hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
 

@@ -86,6 +86,7 @@ struct kvq_scan {
     unsigned long long *d_blob_n = nullptr, *d_err = nullptr, *d_err_stage = nullptr, *d_stage_ctr = nullptr;
     int path_bits = 0;
     std::vector<int64_t> cur_chunk_off;  // chunk offsets of the batch being enqueued
+    size_t cur_co_at = 0;                // ... and where run_batch put them in the pool
     TablePool pool;
     // staging for host batches
     DevBuf d_stage;

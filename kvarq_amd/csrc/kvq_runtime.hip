@@ -193,7 +193,7 @@ static const size_t SMALL_RANGE = 64, SMALL_FAIL = SMALL_RANGE + 4 * (KVQ_MAX_BA
 // everything the batch appended to the hit arena (the host rescans it exhaustively)
 extern "C" __global__ void __launch_bounds__(256)
 kvq_commit_batch(unsigned long long *stage, unsigned long long *ctr, unsigned long long *err_stage, unsigned long long *err,
-                 const unsigned int *fail, unsigned int *arena_n, const unsigned int *range_begin)
+                 const unsigned int *fail, unsigned int *arena_n, unsigned int *range)
 {
     const bool bad = *fail != 0u;
     for (int i = threadIdx.x; i < KVQ_STAGE_SLOTS; i += blockDim.x) {
@@ -202,18 +202,31 @@ kvq_commit_batch(unsigned long long *stage, unsigned long long *ctr, unsigned lo
         stage[i] = 0;
     }
     if (threadIdx.x == 0) {
-        if (bad) *arena_n = *range_begin;
+        if (bad) *arena_n = range[0];
         else if (*err_stage != ~0ull) atomicMin(err, *err_stage);
         *err_stage = ~0ull;
+        range[1] = *arena_n;                       // the batch's hits end here
     }
+}
+
+// the scan's device state back to "nothing scanned" in one launch: the small words (err and the
+// staged err to all ones), counters, coverage marks (all 8-byte words)
+extern "C" __global__ void __launch_bounds__(256)
+kvq_reset_state(unsigned long long *small, size_t small_words, unsigned long long *ctr, size_t ctr_words,
+                unsigned long long *cov, size_t cov_words)
+{
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < small_words; i += step) small[i] = (i == 2 || i == 3) ? ~0ull : 0ull;      // bytes 16..31: err, staged err
+    for (size_t i = i0; i < ctr_words; i += step) ctr[i] = 0ull;
+    for (size_t i = i0; i < cov_words; i += step) cov[i] = 0ull;
 }
 
 static int reset_device_state(kvq_scan *s)
 {
-    KVQ_HIP(hipMemsetAsync(s->d_small.p, 0, SMALL_BYTES, s->stream));
-    KVQ_HIP(hipMemsetAsync(s->d_err, 0xFF, 16, s->stream));       // err and the staged err
-    KVQ_HIP(hipMemsetAsync(s->d_ctr, 0, (size_t)s->t->ctr_len * 8, s->stream));
-    KVQ_HIP(hipMemsetAsync(s->d_covdiff.p, 0, ((size_t)s->t->bases + (size_t)s->t->nseq + 1) * 8, s->stream));
+    static_assert(SMALL_BYTES % 8 == 0, "kvq_reset_state writes 8-byte words");
+    hipLaunchKernelGGL(kvq_reset_state, dim3(256), dim3(256), 0, s->stream, (unsigned long long *)s->d_small.p, SMALL_BYTES / 8,
+                       s->d_ctr, (size_t)s->t->ctr_len, s->d_covdiff.as<unsigned long long>(), (size_t)s->t->bases + (size_t)s->t->nseq + 1);
+    KVQ_HIP(hipGetLastError());
     return KVQ_OK;
 }
 
@@ -354,8 +367,13 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
 
     // chunk table: written into the pinned half of the pool, copied to its device half (async)
     int rc;
-    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 4 + 4096, s->stream))) return rc;
+    // (room for everything this batch puts into the pool -- chunk offsets here; first tiles, parameter
+    // block, tile table and tile reports in kvq_seeded_launch, whose tiles own at least ST_TILE bytes --
+    // is made in one go: the pool must not move between the two)
+    const size_t tiles_bound = (size_t)(nbytes / std::min<uint32_t>(ST_TILE, kvq_choose_tile(1u << 20))) + (size_t)nchunks + 2;
+    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 8 + tiles_bound * 20 + 16384, s->stream))) return rc;
     const size_t co_at = s->pool.take(((size_t)nchunks + 1) * 4);
+    s->cur_co_at = co_at;
     uint32_t *co = reinterpret_cast<uint32_t *>(s->pool.h + co_at);
     const uint32_t *d_co = reinterpret_cast<const uint32_t *>(s->pool.d + co_at);
     std::vector<uint32_t> sb((size_t)nchunks + 1);
@@ -373,7 +391,8 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
         maxseg = std::max(maxseg, n); maxchunk = std::max(maxchunk, b - a);
     }
     sb[nchunks] = (uint32_t)segs;
-    KVQ_HIP(hipMemcpyAsync(s->pool.d + co_at, co, ((size_t)nchunks + 1) * 4, hipMemcpyHostToDevice, s->stream));
+    // (the seed-filter launch copies the chunk offsets together with its own tables: one transfer)
+    if (!use_seeded) KVQ_HIP(hipMemcpyAsync(s->pool.d + co_at, co, ((size_t)nchunks + 1) * 4, hipMemcpyHostToDevice, s->stream));
 
     if ((rc = new_event_pair(s->ev_all))) return rc;
     KVQ_HIP(hipEventRecord(s->ev_all.back().first, s->stream));
@@ -439,11 +458,12 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
             }
         }
     }
+    // hits of this batch = arena[range[batch_no], range[batch_no + 1]) (kvq_commit_batch closes the range)
     if (use_seeded)
         hipLaunchKernelGGL(kvq_commit_batch, dim3(1), dim3(256), 0, s->stream, s->d_stage_ctr, s->d_ctr, s->d_err_stage, s->d_err,
-                           (const unsigned int *)(s->d_fail + batch_no), s->d_arena_n, (const unsigned int *)(s->d_range + batch_no));
-    // hits of this batch = arena[range[batch_no], range[batch_no + 1])
-    KVQ_HIP(hipMemcpyAsync(s->d_range + batch_no + 1, s->d_arena_n, 4, hipMemcpyDeviceToDevice, s->stream));
+                           (const unsigned int *)(s->d_fail + batch_no), s->d_arena_n, s->d_range + batch_no);
+    else
+        KVQ_HIP(hipMemcpyAsync(s->d_range + batch_no + 1, s->d_arena_n, 4, hipMemcpyDeviceToDevice, s->stream));
     hipLaunchKernelGGL(kvq_fold_offsets, dim3(64), dim3(256), 0, s->stream, P,
                        (const unsigned int *)(s->d_range + batch_no), (const unsigned int *)(s->d_range + batch_no + 1));
     hipLaunchKernelGGL(kvq_fold_hits, dim3(512), dim3(256), 0, s->stream, P, d_data, fpos_base,
