@@ -66,7 +66,7 @@ def main():
     ap.add_argument('--table', default='MTBC', choices=['MTBC', 'MTBC+barcodes'])
     ap.add_argument('--table-scale', type=int, default=1)
     ap.add_argument('--exhaustive', action='store_true', help='force the exhaustive kernel for every sequence')
-    ap.add_argument('--batch-bytes', type=int, default=(1 << 31) - (1 << 20), help='largest batch handed to kvq_scan_device')
+    ap.add_argument('--batch-bytes', type=int, default=(1 << 32) - (1 << 20), help='largest batch handed to kvq_scan_device')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of the CPU baseline sample')
     args = ap.parse_args()
@@ -122,7 +122,7 @@ def main():
     if real is not None and k > 1:
         assert list(real[:k]) == list(offs[:k]), 'analytic chunk cuts disagree with the chunker'
 
-    # equal batches of at most --batch-bytes (the library takes < 2 GiB per call), cut at chunk
+    # equal batches of at most --batch-bytes (the library takes 4 GiB - 1 MiB per call), cut at chunk
     # boundaries; the base pointer is aligned down to 16 bytes
     nb = max(1, -(-(n * rb) // args.batch_bytes))
     nch = len(offs) - 1

@@ -118,7 +118,7 @@ int64_t kvq_chunk_offsets(const uint8_t *data, int64_t nbytes, int64_t *offsets,
  * offsets into d_data; every chunk starts a fresh record count like one
  * fastq_read buffer.  fpos_base = offset of d_data[0] in the concatenated
  * inflated stream (file_pos of a Hit is global, workhorse.c:777).  nbytes must
- * be < 2^31.  Launches are asynchronous; d_data must stay valid until
+ * be at most 4 GiB - 1 MiB (offsets inside a batch are 32-bit).  Launches are asynchronous; d_data must stay valid until
  * kvq_scan_finish.  Returns KVQ_OK or an error code. */
 int32_t kvq_scan_device(kvq_scan *s, const void *d_data, int64_t nbytes,
                         const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base);

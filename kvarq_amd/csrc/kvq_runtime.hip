@@ -352,7 +352,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     const kvq_table *t = s->t;
     const double tb0 = now_ms();
     if (nbytes <= 0 || nchunks <= 0) return KVQ_OK;
-    if (nbytes >= (1ll << 31)) { kvq_set_error(KVQ_ERR_RUNTIME, "batch of %lld bytes is too large (< 2 GiB)", (long long)nbytes); return KVQ_ERR_RUNTIME; }
+    if (nbytes > 0xFFF00000ll) { kvq_set_error(KVQ_ERR_RUNTIME, "batch of %lld bytes is too large (< 4 GiB - 1 MiB)", (long long)nbytes); return KVQ_ERR_RUNTIME; }
     if (batch_no >= KVQ_MAX_BATCHES) { kvq_set_error(KVQ_ERR_RUNTIME, "too many batches in one scan"); return KVQ_ERR_RUNTIME; }
     if (((uintptr_t)d_data & 15u) != 0) { kvq_set_error(KVQ_ERR_RUNTIME, "device buffer must be 16-byte aligned"); return KVQ_ERR_RUNTIME; }
 

