@@ -149,7 +149,7 @@ def main():
         scanner.reset()
         for base, nbytes, co in batches:
             scanner.scan_device(d_data.ptr + base, nbytes, co, fpos_base=fpos0 + base)
-        r = scanner.finish(hits=False)      # hits, hit bytes and counters are on the host (C arrays); no Python tuples here
+        r = scanner.finish(hits=False, stats=False)     # hits, hit bytes and counters are on the host (C arrays); no Python tuples or dicts here
         if world > 1:
             kdist.reduce_counters(ctr, dist)                            # hit/coverage arrays over xGMI (one sum all-reduce)
             torch.cuda.current_stream().synchronize()                   # the next step zeroes ctr on the scan's own stream
@@ -183,9 +183,10 @@ def main():
         total_records = int(ctr[_lib.CTR_RECORDS].item())
         total_hits = int(ctr[_lib.CTR_HITS].item())
     else:
-        total_records = r['stats']['records_parsed']
+        total_records = int(r['counters'][_lib.CTR_RECORDS])
         total_hits = r['n_hits']
-    assert r['stats']['records_parsed'] == n, 'records lost: %d of %d' % (r['stats']['records_parsed'], n)
+    # (with several ranks r['counters'] is the rank's own view of the reduced device tensor's host copy: per-rank records)
+    assert int(r['counters'][_lib.CTR_RECORDS]) == n, 'records lost: %d of %d' % (int(r['counters'][_lib.CTR_RECORDS]), n)
 
     if rank != 0:
         if world > 1:

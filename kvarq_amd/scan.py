@@ -97,12 +97,18 @@ class Scanner(object):
         _check(_lib.lib().kvq_scan_host(self.h, arr.ctypes.data if arr.nbytes else None, arr.nbytes,
                                         co.ctypes.data_as(C.POINTER(C.c_int64)), len(co) - 1, fpos_base))
 
-    def finish(self, hits=True):
-        """-> dict with 'hits', 'hitseqs' (bytes), 'stats', 'coverage', 'mutations', 'counters'"""
+    def finish(self, hits=True, stats=True):
+        """-> dict with 'hits', 'hitseqs' (bytes), 'stats', 'coverage', 'mutations', 'counters'.
+
+        ``hits=False`` leaves hits and hit bytes in the library's arrays (``kvq_scan_hit_*``), ``stats=False``
+        also skips the Python ``stats`` dict and hands out ``counters`` as a view of the library's host
+        array (valid until the next ``reset`` / ``close``) -- for callers that only reduce counters."""
         L = _lib.lib()
         _check(L.kvq_scan_finish(self.h))
         t = self.table
-        ctr = np.ctypeslib.as_array(L.kvq_scan_counters(self.h), shape=(t.counters_len,)).copy()
+        ctr = np.ctypeslib.as_array(L.kvq_scan_counters(self.h), shape=(t.counters_len,))
+        if stats:
+            ctr = ctr.copy()
         out = {'counters': ctr}
         nh = L.kvq_scan_n_hits(self.h)
         out['n_hits'] = nh
@@ -113,6 +119,11 @@ class Scanner(object):
             off = L.kvq_scan_hitseq_offsets(self.h)
             blob = C.string_at(L.kvq_scan_hitseq_blob(self.h), off[nh]) if nh else b''
             out['hitseqs'] = [blob[off[i]:off[i + 1]] for i in range(nh)]
+        out['kernel_ms'] = L.kvq_scan_kernel_ms(self.h)
+        out['main_kernel_ms'] = L.kvq_scan_main_kernel_ms(self.h)
+        out['main_kernel_launches'] = L.kvq_scan_main_kernel_launches(self.h)
+        if not stats:
+            return out
         longest = int(ctr[_lib.CTR_LONGEST]) - 1
         parsed, total = L.kvq_scan_parsed(self.h), L.kvq_scan_total(self.h)
         rls = ctr[_lib.CTR_READLENGTHS:_lib.CTR_READLENGTHS + _lib.MAX_READLENGTH]
@@ -125,9 +136,6 @@ class Scanner(object):
         }
         out['coverage'] = ctr[t.off_coverage:t.off_coverage + t.bases]
         out['mutations'] = ctr[t.off_mutations:t.off_mutations + 6 * t.bases]
-        out['kernel_ms'] = L.kvq_scan_kernel_ms(self.h)
-        out['main_kernel_ms'] = L.kvq_scan_main_kernel_ms(self.h)
-        out['main_kernel_launches'] = L.kvq_scan_main_kernel_launches(self.h)
         path = L.kvq_scan_path(self.h)
         out['path'] = {'seeded': bool(path & 1), 'exhaustive': bool(path & 2), 'rescanned': bool(path & 4)}
         return out
