@@ -78,6 +78,28 @@ kvq_bucket_sort(const KvqHit *__restrict__ arena, KvqBucketPlan B, const uint32_
     if (m < 2u) return;
     if (m > KVQ_BUCKET_MAX) { *crowded = 1u; return; }
     const KvqHitBefore before;
+    if (m <= 8u) {
+        // the usual bucket: its hits are fetched side by side (not one per comparison) and sorted in registers
+        uint32_t ix[8]; KvqHit h[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) ix[i] = (uint32_t)i < m ? idx[s0 + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if ((uint32_t)i < m) h[i] = arena[ix[i]];
+        // odd-even transposition network over the first m of 8 slots (no dynamic register indexing)
+#pragma unroll
+        for (int round = 0; round < 8; round++) {
+#pragma unroll
+            for (int i = round & 1; i + 1 < 8; i += 2) {
+                if ((uint32_t)(i + 1) < m && before(h[i + 1], h[i])) {
+                    const KvqHit th = h[i]; h[i] = h[i + 1]; h[i + 1] = th;
+                    const uint32_t ti = ix[i]; ix[i] = ix[i + 1]; ix[i + 1] = ti;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) if ((uint32_t)i < m) idx[s0 + i] = ix[i];
+        return;
+    }
     for (uint32_t i = 1; i < m; i++) {
         const uint32_t x = idx[s0 + i]; const KvqHit hx = arena[x];
         uint32_t j = i;
@@ -131,7 +153,7 @@ static int kvq_order_results(hipStream_t stream, const KvqHit *arena, uint32_t n
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 3) / 4, 8192);
     if (by_buckets) {
         KvqBucketPlan B; B.lo = lo;
-        uint32_t want = 256; while (want < n && want < (1u << 22)) want <<= 1;
+        uint32_t want = 256; while (want < 4ull * n && want < (1u << 22)) want <<= 1;      // about four buckets per hit: most hold none or one
         const uint64_t span = (uint64_t)(hi > lo ? hi - lo : 1);
         B.shift = 0; while ((span >> B.shift) >= (uint64_t)want) B.shift++;
         B.nb = (uint32_t)(span >> B.shift) + 1u;                           // <= want
