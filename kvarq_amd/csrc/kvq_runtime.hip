@@ -221,6 +221,16 @@ kvq_reset_state(unsigned long long *small, size_t small_words, unsigned long lon
     for (size_t i = i0; i < cov_words; i += step) cov[i] = 0ull;
 }
 
+// the scan's eight small words and its per-batch "speculation failed" flags -> pinned host memory
+extern "C" __global__ void __launch_bounds__(256)
+kvq_publish_small(const unsigned int *__restrict__ small, const unsigned int *__restrict__ fail, unsigned int nbatches,
+                  unsigned int *host_small, unsigned int *host_fail)
+{
+    if (threadIdx.x < 8) host_small[threadIdx.x] = small[threadIdx.x];
+    for (unsigned int i = threadIdx.x; i < nbatches; i += blockDim.x) host_fail[i] = fail[i];
+    __threadfence_system();
+}
+
 static int reset_device_state(kvq_scan *s)
 {
     static_assert(SMALL_BYTES % 8 == 0, "kvq_reset_state writes 8-byte words");
@@ -560,8 +570,11 @@ static int finish_once(kvq_scan *s)
     const size_t nb0 = s->batches.size();
     unsigned char *small = s->pin_small; unsigned int *fail = reinterpret_cast<unsigned int *>(s->pin_small + 64);
     auto fetch_small = [&]() -> int {
-        KVQ_HIP(hipMemcpyAsync(small, s->d_small.p, 32, hipMemcpyDeviceToHost, s->stream));
-        if (!s->batches.empty()) KVQ_HIP(hipMemcpyAsync(fail, s->d_fail, s->batches.size() * 4, hipMemcpyDeviceToHost, s->stream));
+        // one small kernel stores the words straight into the pinned host buffer (two copy
+        // engine transfers would each cost a launch)
+        hipLaunchKernelGGL(kvq_publish_small, dim3(1), dim3(256), 0, s->stream, (const unsigned int *)s->d_small.p,
+                           (const unsigned int *)s->d_fail, (unsigned int)s->batches.size(), (unsigned int *)small, fail);
+        KVQ_HIP(hipGetLastError());
         KVQ_HIP(hipStreamSynchronize(s->stream));
         return KVQ_OK;
     };
