@@ -159,6 +159,15 @@ def test_a_batch_beyond_2_gib_equals_the_same_text_in_two_batches():
     assert one['n_hits'] == two['n_hits'] > 20000 and one['hits'] == two['hits'] and one['hitseqs'] == two['hitseqs']
     assert (one['counters'] == two['counters']).all()
     assert max(h.file_pos for h in one['hits']) > (1 << 31)
+    assert sum(one['stats']['readlengths']) == n
+    # ... and == the exhaustive kernels on the same 2.3 GB (every workgroup walks ~110 tiles drawn from the
+    # tile counter and flushes its read-length histogram on the way; nothing of that exists on the other path)
+    s.reset()
+    s.force_exhaustive(True)
+    s.scan_device(dd.ptr, n * rb, co)
+    three = s.finish()
+    assert three['path'] == dict(seeded=False, exhaustive=True, rescanned=False)
+    assert one['hits'] == three['hits'] and one['hitseqs'] == three['hitseqs'] and (one['counters'] == three['counters']).all()
     s.close(); t.close(); dd.free(); dg.free()
 
 
