@@ -97,7 +97,14 @@ public:
         consumed_ = 0; file_done_ = false;
         fseek(fd_, 0, SEEK_END); file_size_ = ftell(fd_); fseek(fd_, 0, SEEK_SET);
         gz_ = name.size() >= 3 && name.compare(name.size() - 3, 3, ".gz") == 0;     // by suffix (582)
+        bgzf_ = false;
         if (gz_) {
+            // a file of BGZF blocks (bgzip: gzip members of at most 64 KiB that carry their own size)
+            // is inflated by `nthreads` workers, block by block; anything else by the serial path below,
+            // which also takes over should a later member not be a BGZF block
+            BgzfBlock first;
+            const char *sw = getenv("KVQ_BGZF");                              // KVQ_BGZF=0: serial reader only (diagnostic)
+            if (!(sw && sw[0] == '0') && bgzf_peek(0, &first)) { bgzf_ = true; boff_ = 0; total_ *= 3; return KVQ_OK; }
             memset(&zs_, 0, sizeof(zs_));
             if (inflateInit2(&zs_, -MAX_WBITS) != Z_OK) { kvq_set_error(KVQ_ERR_RUNTIME, "cannot mz_inflateInit()"); return KVQ_ERR_RUNTIME; }
             zs_live_ = true;
@@ -147,6 +154,10 @@ public:
             if (n < cap) { *eof = true; file_done_ = true; }
             consumed_ += n;
         } else {
+            if (bgzf_) {
+                const int64_t got = read_bgzf(dst, cap, eof);
+                if (got != -2) return got;            // -2: the next member is no BGZF block -> serial path from here on
+            }
             zs_.next_out = dst; zs_.avail_out = (uInt)cap;
             bool done = false;
             while (zs_.avail_out > 0 && !done) {
@@ -196,6 +207,113 @@ public:
     int64_t total() const { return total_; }
 
 private:
+    // ---- BGZF (SAM/BAM specification, section 4.1): gzip member with FEXTRA subfield 'B','C',2,0,BSIZE ----
+    struct BgzfBlock { int64_t off; uint32_t size, hdr, isize; };       // file offset, block bytes, header bytes, inflated bytes
+
+    // is there a well-formed BGZF block at file offset `off`?
+    bool bgzf_peek(int64_t off, BgzfBlock *b)
+    {
+        uint8_t h[12];
+        const int fdn = fileno(fd_);
+        if (off + 28 > file_size_ || pread(fdn, h, 12, (off_t)off) != 12) return false;
+        if (h[0] != 0x1F || h[1] != 0x8B || h[2] != 8 || h[3] != 4) return false;             // exactly FEXTRA, as bgzip writes
+        const uint32_t xlen = h[10] | (h[11] << 8);
+        if (xlen < 6 || xlen > 4096) return false;
+        uint8_t x[4096];
+        if (pread(fdn, x, xlen, (off_t)(off + 12)) != (ssize_t)xlen) return false;
+        uint32_t bsize = 0;
+        for (uint32_t i = 0; i + 4 <= xlen; ) {
+            const uint32_t slen = x[i + 2] | (x[i + 3] << 8);
+            if (x[i] == 'B' && x[i + 1] == 'C' && slen == 2 && i + 6 <= xlen) bsize = (x[i + 4] | (x[i + 5] << 8)) + 1u;
+            i += 4 + slen;
+        }
+        const uint32_t hdr = 12 + xlen;
+        if (bsize < hdr + 8 || off + bsize > file_size_) return false;
+        uint8_t t[4];
+        if (pread(fdn, t, 4, (off_t)(off + bsize - 4)) != 4) return false;
+        b->off = off; b->size = bsize; b->hdr = hdr;
+        b->isize = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+        return b->isize <= 65536;
+    }
+
+    // inflate as many whole BGZF blocks as fit into cap bytes, nthreads workers; -2 = hand over to the serial path
+    int64_t read_bgzf(uint8_t *dst, int64_t cap, bool *eof)
+    {
+        std::vector<BgzfBlock> blocks;
+        int64_t out = 0;
+        bool handover = false;
+        while (true) {
+            if (file_size_ - boff_ <= 10) {                                               // at most a trailer is left (workhorse.c:842)
+                consumed_ += file_size_ - boff_; boff_ = file_size_;                      // (the serial reader has read those bytes too)
+                *eof = true; file_done_ = true; break;
+            }
+            BgzfBlock b;
+            if (!bgzf_peek(boff_, &b)) { handover = true; break; }
+            if (out + b.isize > cap) break;
+            blocks.push_back(b); out += b.isize; boff_ += b.size;
+        }
+        if (handover && blocks.empty()) {
+            // the serial reader continues at this member: position the file, skip its header as open_next does
+            bgzf_ = false;
+            memset(&zs_, 0, sizeof(zs_));
+            if (inflateInit2(&zs_, -MAX_WBITS) != Z_OK) { kvq_set_error(KVQ_ERR_RUNTIME, "cannot mz_inflateInit()"); return -1; }
+            zs_live_ = true;
+            if (!inbuf_) inbuf_ = (uint8_t *)malloc(KVQ_SCANBUFSIZE);
+            if (!inbuf_) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate inbuf"); return -1; }
+            fseek(fd_, (long)boff_, SEEK_SET);
+            remaining_ = file_size_ - boff_;
+            const int64_t before = consumed_;
+            const char *msg = skip_gz_header(10);
+            if (msg) { *eof = true; file_done_ = true; return 0; }          // as behind any member: no further header, the stream ends (851-853)
+            remaining_ -= consumed_ - before;
+            return -2;
+        }
+        // read the compressed bytes of the whole run once, then inflate block by block in parallel
+        if (!blocks.empty()) {
+            const int64_t c0 = blocks.front().off, c1 = blocks.back().off + blocks.back().size;
+            cbuf_.resize((size_t)(c1 - c0));
+            const int fdn = fileno(fd_);
+            for (int64_t a = 0; a < c1 - c0; ) {
+                const ssize_t got = pread(fdn, cbuf_.data() + a, (size_t)(c1 - c0 - a), (off_t)(c0 + a));
+                if (got <= 0) { kvq_set_error(KVQ_ERR_IO, "could not read enough bytes from .fastq.gz : I/O error"); return -1; }
+                a += got;
+            }
+            std::vector<int64_t> at(blocks.size());
+            int64_t o = 0;
+            for (size_t i = 0; i < blocks.size(); i++) { at[i] = o; o += blocks[i].isize; }
+            kvq_config cfg; kvq_config_get(&cfg);
+            int nt = cfg.nthreads < 1 ? 1 : (cfg.nthreads > 32 ? 32 : cfg.nthreads);
+            if ((size_t)nt > blocks.size()) nt = (int)blocks.size();
+            std::atomic<int> bad{0};
+            auto work = [&](int t) {
+                z_stream z; memset(&z, 0, sizeof(z));
+                if (inflateInit2(&z, -MAX_WBITS) != Z_OK) { bad = 1; return; }
+                for (size_t i = blocks.size() * t / nt; i < blocks.size() * (t + 1) / nt; i++) {
+                    const BgzfBlock &b = blocks[i];
+                    z.next_in = cbuf_.data() + (b.off - c0) + b.hdr; z.avail_in = b.size - b.hdr - 8;
+                    z.next_out = dst + at[i]; z.avail_out = b.isize;
+                    const int st = inflate(&z, Z_FINISH);
+                    if (st != Z_STREAM_END || z.avail_out != 0) { bad = (st == Z_STREAM_END || st == Z_OK || st == Z_BUF_ERROR) ? 2 : 3; break; }
+                    inflateReset(&z);
+                }
+                inflateEnd(&z);
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+            if (bad.load()) {
+                kvq_set_error(KVQ_ERR_IO, "error while inflating compressed data : status=%d fpos=%ld", bad.load() == 3 ? Z_DATA_ERROR : Z_BUF_ERROR, (long)fpos_);
+                return -1;
+            }
+            consumed_ += c1 - c0;
+        }
+        if (ftell0_ + consumed_ > 0)
+            total_ = (int64_t)(size_t)((float)size_ * (fpos_ + out) / (ftell0_ + consumed_));      // as in the serial path (883-884)
+        fpos_ += out;
+        return out;
+    }
+
     int getc_counted() { const int c = fgetc(fd_); if (c != EOF) consumed_++; return c; }
 
     // workhorse.c:482-541
@@ -227,6 +345,7 @@ private:
     std::vector<std::string> files_; size_t next_ = 0;
     FILE *fd_ = nullptr; bool gz_ = false, file_done_ = true;
     z_stream zs_; bool zs_live_ = false; uint8_t *inbuf_ = nullptr; int64_t remaining_ = 0;
+    bool bgzf_ = false; int64_t boff_ = 0; std::vector<uint8_t> cbuf_;       // BGZF: next block's file offset, compressed run
     int64_t size_ = 0, ftell0_ = 0, consumed_ = 0, fpos_ = 0, total_ = 0, file_size_ = 0;
 };
 

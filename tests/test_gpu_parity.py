@@ -171,6 +171,24 @@ def test_a_batch_beyond_2_gib_equals_the_same_text_in_two_batches():
     s.close(); t.close(); dd.free(); dg.free()
 
 
+def test_bgzf_file_equals_the_oracle_on_the_same_file(tmp_path):
+    """a bgzip'ed FastQ (inflated block-parallel on the host) against the oracle's serial zlib reader: hits, bytes, all stats"""
+    from test_host_logic import bgzf
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g))
+    data = synth.reads(g, 777, 40000, 150).tobytes()
+    p = str(tmp_path / 'reads.fastq.gz')
+    open(p, 'wb').write(bgzf(data, level=1))
+    for nt in (1, 8):
+        cfg = dict(cases.PRODUCT, nthreads=nt)
+        engine.config(**cfg)
+        r = engine.findseqs(p, seqs)
+        o = O.findseqs(p, seqs, **cfg)
+        assert tuple(r['hits']) == tuple(o['hits']) and len(r['hits']) > 50
+        assert [bytes(h) for h in r['hitseqs']] == o['hitseqs']
+        assert r['stats'] == o['stats']
+
+
 def test_hit_arena_overflow_is_transparent():
     """more hits than the initial arena holds: rescan with a larger one, same result"""
     read = 'ACG' * 60

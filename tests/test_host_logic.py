@@ -186,3 +186,47 @@ def test_reader_with_parallel_pread(tmp_path):
     finally:
         engine.config(**saved)
     assert got == expected_plan([big]) and parsed == total == len(big)
+
+
+def bgzf(data, block=60000, level=6):
+    """the bytes as a BGZF file (bgzip): gzip members of at most 64 KiB with the 'BC' extra subfield, then the empty EOF block"""
+    import struct, zlib
+    out = []
+    for i in range(0, len(data), block):
+        chunk = data[i:i + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        raw = co.compress(chunk) + co.flush()
+        out.append(b'\x1f\x8b\x08\x04\0\0\0\0\x00\xff' + struct.pack('<H', 6) + b'BC' + struct.pack('<HH', 2, len(raw) + 25) +
+                   raw + struct.pack('<II', zlib.crc32(chunk), len(chunk)))
+    out.append(bytes.fromhex('1f8b08040000000000ff0600424302001b0003000000000000000000'))
+    return b''.join(out)
+
+
+@pytest.mark.parametrize('nthreads', [1, 4])
+def test_bgzf_blocks_are_inflated_in_parallel_to_the_same_stream(tmp_path, nthreads):
+    """bgzip'ed FastQ (multi-member gzip, workhorse.c:842-866) gives the chunks of the plain text, also when
+    ordinary gzip members follow the blocks (the serial reader takes over) and with trailing bytes"""
+    L = _lib.lib()
+    from kvarq_amd import engine
+    engine.config(**dict(cases.PRODUCT, nthreads=nthreads))
+    big = cases.multichunk()
+    other = cases.ragged(34, 4000, cases.RAGGED_TARGETS)
+    p1, p2, p3 = str(tmp_path / 'a.fastq.gz'), str(tmp_path / 'b.fastq.gz'), str(tmp_path / 'c.fastq.gz')
+    z1 = bgzf(big)
+    open(p1, 'wb').write(z1)
+    z2 = bgzf(other[:len(other) // 2])[:-28] + gzip.compress(other[len(other) // 2:], mtime=0)      # blocks, then one plain member
+    open(p2, 'wb').write(z2)
+    open(p3, 'wb').write(bgzf(b'@tail\nACGT', block=7) + b'\0\0\0')                                   # tiny blocks, trailing bytes
+    got, (parsed, total) = plan([p1, p2, p3])
+    assert got == expected_plan([big, other, b'@tail\nACGT'])
+    assert parsed == len(big) + len(other) + 10
+    # chunks, parsed bytes and the final size estimate (float arithmetic, workhorse.c:883-884) == the serial reader's,
+    # which the reference's own .gz outcomes pin (test_reader_stats_match_the_reference_on_gz)
+    os.environ['KVQ_BGZF'] = '0'
+    try:
+        serial = plan([p1, p2, p3])
+    finally:
+        del os.environ['KVQ_BGZF']
+    assert serial == (got, (parsed, total))
+    got, (parsed, total) = plan([p1], 1 << 20)
+    assert got == expected_plan([big]) and parsed == len(big)

@@ -37,4 +37,18 @@ t0 = time.perf_counter()
 r = engine.findseqs(gzpath, seqs)
 dt = time.perf_counter() - t0
 print('gzip   200k reads     %.3f s  %.2f M reads/s (single-threaded inflate)  hits=%d' % (dt, 0.2 / dt, len(r['hits'])))
-os.remove(path); os.remove(gzpath)
+# the same text bgzip'ed (BGZF blocks of 60000 bytes): block-parallel inflate
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+from test_host_logic import bgzf  # noqa: E402
+nb = 1_000_000
+bpath = '/tmp/kvq_rate_bgzf.fastq.gz'
+with open(bpath, 'wb') as f:
+    f.write(bgzf(data[:nb * rb].tobytes(), level=1))
+for nt in (1, 4, 16):
+    engine.config(maxerrors=2, minoverlap=25, minreadlength=25, Amin='.', nthreads=nt)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        r = engine.findseqs(bpath, seqs)
+        dt = time.perf_counter() - t0
+    print('bgzf   nthreads=%2d  %.3f s  %.1f M reads/s  %.2f GB/s inflated  hits=%d' % (nt, dt, nb / dt / 1e6, nb * rb / dt / 1e9, len(r['hits'])))
+os.remove(path); os.remove(gzpath); os.remove(bpath)
