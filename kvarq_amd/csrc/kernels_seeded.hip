@@ -474,9 +474,9 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 const uint4 *__restrict__ tiles, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg,
                 uint32_t tile_bytes, unsigned int *__restrict__ tile_ctr)
 {
-    extern __shared__ __align__(16) uint8_t lds_raw[];
-    SeededLds &S = *reinterpret_cast<SeededLds *>(lds_raw);
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ __align__(16) SeededLds S;
+    uint8_t *const lds_raw = reinterpret_cast<uint8_t *>(&S);
+    int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = rfl((uint32_t)tid >> 6);
     if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t *)lds_raw) != 0u) __builtin_trap();   // lds_byte_at
     // the issue arbiter prefers the older wave of a SIMD, so waves 4..7 (the second wave of the
@@ -521,6 +521,11 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
     uint32_t gn = rfl(S.next_tile);
     for (uint32_t g = blockIdx.x; g < ntiles; ) {
         const TileGeo J = tile_geo(g, tiles, tile_bytes);
+        // the thread number is made opaque once per tile: the lane masks derived from it ("thread 0",
+        // "lane 63", ...) are then worked out where they are used (one compare) instead of being kept
+        // in scalar registers across the whole loop, which the kernel has run out of
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
         if constexpr (STAMPS) stamp_t = __builtin_amdgcn_s_memtime();
         // every vector load has to be back here anyway; saying so on all paths keeps the
         // compiler from waiting for the next tile's loads in the middle of this tile
@@ -587,16 +592,15 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         STAMP(1);
         uint32_t n_all = 0;
         {
-            uint32_t mine = 0;
-            uint32_t tot[ST_WAVES];
-            {
-                // two 16-byte LDS reads instead of eight dword reads
-                const uint4 a0 = reinterpret_cast<const uint4 *>(S.wtot)[0], a1 = reinterpret_cast<const uint4 *>(S.wtot)[1];
-                tot[0] = a0.x; tot[1] = a0.y; tot[2] = a0.z; tot[3] = a0.w; tot[4] = a1.x; tot[5] = a1.y; tot[6] = a1.z; tot[7] = a1.w;
-            }
-#pragma unroll
-            for (int w = 0; w < ST_WAVES; w++) { if (w == (int)wave) mine = n_all; n_all += tot[w]; }
-            uint32_t n = mine + incl - cnt;
+            // lanes 0..7 hold the eight wave totals; three DPP adds make their running sums, two lane
+            // reads pick this wave's and the last one (no per-wave masks to keep in scalar registers)
+            uint32_t run = S.wtot[lane & 7];
+            run += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)run, 0x111, 0xf, 0xf, false);
+            run += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)run, 0x112, 0xf, 0xf, false);
+            run += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)run, 0x114, 0xf, 0xf, false);
+            n_all = (uint32_t)__builtin_amdgcn_readlane((int)run, 7);
+            const uint32_t upto = (uint32_t)__builtin_amdgcn_readlane((int)run, (int)wave);      // ... including this wave
+            uint32_t n = upto - (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) + incl - cnt;
             // newlines the tile owns = those up to the end of its last owned block (own_end_l is a block
             // boundary or the end of the text): the thread of that block knows the count
             if (blk < own_end_l && blk + ST_BLK >= own_end_l) S.n_owned = n + cnt;
@@ -615,7 +619,6 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 }
             }
         }
-        n_all = rfl(n_all);
         __syncthreads();
         STAMP(2);
         // the tile after next: drawn here, behind the last barrier before the long barrier-free stretch
@@ -664,6 +667,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
             }
         }
 
+        if (dbg & 32u) nrec = 0;                                     // diagnostic: front end only
         STAMP(3);
         if (younger) __builtin_amdgcn_s_setprio(2);
         unsigned long long wave_t3 = 0;
@@ -1164,7 +1168,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     } else {
         const uint32_t grid = grid_seeded;
         const SeededKernel kern = kernels[(ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0) + ((dbg & 16u) ? 3 : 0)];
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), sizeof(SeededLds), s->stream, d_params, ix->dev, d_data, fpos_base,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), 0, s->stream, d_params, ix->dev, d_data, fpos_base,
                            reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg, TILE, d_tile_ctr);
     }
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,

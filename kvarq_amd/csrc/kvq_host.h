@@ -98,7 +98,7 @@ struct kvq_scan {
     int64_t records = 0;
     int64_t parsed = 0, total = 0;
     // timing
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_all, ev_main;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_all, ev_main, ev_free;     // ev_free: pairs of earlier scans, reused
     double ms_all = 0, ms_main = 0; int64_t main_launches = 0;
     // results: ordered and laid out on the device (kernels_results.hip), one copy into pinned host memory
     DevBuf d_sort_tmp, d_sorted, d_result;

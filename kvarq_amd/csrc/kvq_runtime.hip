@@ -290,18 +290,21 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     return s;
 }
 
-static void drop_events(kvq_scan *s)
+// timing events are kept for the next scan of the same handle (creating a pair costs several microseconds)
+static void drop_events(kvq_scan *s, bool destroy = false)
 {
-    for (auto &e : s->ev_all) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    for (auto &e : s->ev_main) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    s->ev_all.clear(); s->ev_main.clear();
+    for (auto *v : { &s->ev_all, &s->ev_main }) { s->ev_free.insert(s->ev_free.end(), v->begin(), v->end()); v->clear(); }
+    if (destroy) {
+        for (auto &e : s->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        s->ev_free.clear();
+    }
 }
 
 extern "C" void kvq_scan_destroy(kvq_scan *s)
 {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    drop_events(s);
+    drop_events(s, true);
     if (s->own_ctr && s->d_ctr) (void)hipFree(s->d_ctr);
     if (s->pin) (void)hipHostFree(s->pin);
     if (s->pin_small) (void)hipHostFree(s->pin_small);
@@ -346,8 +349,9 @@ static KvqParams make_params(const kvq_scan *s)
     return P;
 }
 
-static int new_event_pair(std::vector<std::pair<hipEvent_t, hipEvent_t>> &v)
+static int new_event_pair(kvq_scan *s, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v)
 {
+    if (!s->ev_free.empty()) { v.push_back(s->ev_free.back()); s->ev_free.pop_back(); return KVQ_OK; }
     hipEvent_t a, b;
     KVQ_HIP(hipEventCreate(&a)); KVQ_HIP(hipEventCreate(&b));
     v.emplace_back(a, b);
@@ -404,12 +408,12 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     // (the seed-filter launch copies the chunk offsets together with its own tables: one transfer)
     if (!use_seeded) KVQ_HIP(hipMemcpyAsync(s->pool.d + co_at, co, ((size_t)nchunks + 1) * 4, hipMemcpyHostToDevice, s->stream));
 
-    if ((rc = new_event_pair(s->ev_all))) return rc;
+    if ((rc = new_event_pair(s, s->ev_all))) return rc;
     KVQ_HIP(hipEventRecord(s->ev_all.back().first, s->stream));
 
     bool hist_done = false;
     if (use_seeded) {
-        if ((rc = new_event_pair(s->ev_main))) return rc;
+        if ((rc = new_event_pair(s, s->ev_main))) return rc;
         KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream));
         KvqParams PS = P;                          // counters and error of this batch are staged until it is validated
         PS.ctr = s->d_stage_ctr; PS.err = s->d_err_stage;
@@ -461,7 +465,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
                                s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), hist_done ? 0 : 1);
             if (n_exh > 0) {
                 const bool main_here = !use_seeded;
-                if (main_here) { if ((rc = new_event_pair(s->ev_main))) return rc; KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream)); }
+                if (main_here) { if ((rc = new_event_pair(s, s->ev_main))) return rc; KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream)); }
                 hipLaunchKernelGGL(kvq_match_all, dim3((uint32_t)((R + 3) / 4)), dim3(256), 0, s->stream, P, d_data, fpos_base, (uint32_t)R,
                                    s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), d_exh, n_exh);
                 if (main_here) { KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream)); s->main_launches++; }

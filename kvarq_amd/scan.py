@@ -75,6 +75,14 @@ def chunk_offsets(data):
     return np.array(list(out)[:n + 1], dtype=np.int64)
 
 
+def _view(ptr, n, ctype, dtype):
+    """numpy view of a C array the library owns (np.ctypeslib.as_array costs ~60 us per call)"""
+    addr = C.cast(ptr, C.c_void_p).value
+    if not addr or n <= 0:
+        return np.zeros(0, dtype=dtype)
+    return np.frombuffer((ctype * n).from_address(addr), dtype=dtype)
+
+
 class Scanner(object):
     """accumulates hits and counters over any number of batches"""
 
@@ -106,15 +114,17 @@ class Scanner(object):
         L = _lib.lib()
         _check(L.kvq_scan_finish(self.h))
         t = self.table
-        ctr = np.ctypeslib.as_array(L.kvq_scan_counters(self.h), shape=(t.counters_len,))
+        ctr = _view(L.kvq_scan_counters(self.h), t.counters_len, C.c_int64, np.int64)
         if stats:
             ctr = ctr.copy()
         out = {'counters': ctr}
         nh = L.kvq_scan_n_hits(self.h)
         out['n_hits'] = nh
         if hits:
-            a = [np.ctypeslib.as_array(f(self.h), shape=(nh,)).copy() if nh else np.zeros(0, dtype=np.int64)
-                 for f in (L.kvq_scan_hit_seq_nr, L.kvq_scan_hit_file_pos, L.kvq_scan_hit_seq_pos, L.kvq_scan_hit_length, L.kvq_scan_hit_readlength)]
+            a = [_view(f(self.h), nh, ct, dt).copy()
+                 for f, ct, dt in ((L.kvq_scan_hit_seq_nr, C.c_int32, np.int32), (L.kvq_scan_hit_file_pos, C.c_int64, np.int64),
+                                   (L.kvq_scan_hit_seq_pos, C.c_int32, np.int32), (L.kvq_scan_hit_length, C.c_int32, np.int32),
+                                   (L.kvq_scan_hit_readlength, C.c_int32, np.int32))]
             out['hits'] = tuple(Hit(int(a[0][i]), int(a[1][i]), int(a[2][i]), int(a[3][i]), int(a[4][i])) for i in range(nh))
             off = L.kvq_scan_hitseq_offsets(self.h)
             blob = C.string_at(L.kvq_scan_hitseq_blob(self.h), off[nh]) if nh else b''
