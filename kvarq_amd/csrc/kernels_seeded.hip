@@ -281,6 +281,14 @@ __device__ __forceinline__ uint32_t good_flags(uint32_t x, uint32_t addk)
     return __builtin_amdgcn_bitop3_b32((x & 0x7F7F7F7Fu) + addk, 0x80808080u, x, 0x40);               // t & 0x80.. & ~x
 }
 
+// product of two numbers below 2^24 at full rate (v_mul_lo_u32 takes four issue slots)
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // longest run of ones in the low n (1..64) bits of m, first one if several: length, start
 __device__ __forceinline__ void longest_run64(uint64_t m, int n, int &len, int &start)
 {
@@ -702,7 +710,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 // bytes (SWAR, a dword at a time) -> longest run by shifts, no per-byte branching
                 const int Q = (int)(n3 - sscore);                   // the closing '\n' is implied
                 const int per = (Q + (int)G - 1) >> lg;
-                Seg sg; sg.beg = (int)gl * per; if (sg.beg > Q) sg.beg = Q;
+                Seg sg; sg.beg = (int)mul_u24(gl, (uint32_t)per); if (sg.beg > Q) sg.beg = Q;    // (24-bit multiply: full rate)
                 int s1 = sg.beg + per; if (s1 > Q) s1 = Q;
                 sg.len = 0; sg.pre = 0; sg.suf = 0; sg.best = 0; sg.bstart = sg.beg;
                 {
@@ -720,16 +728,15 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                         {
                             // the first 48 bytes in one go (twelve loads travel together; a 150 bp read's
                             // slice needs no more), whatever is left in rounds of 16
-                            uint32_t q[12];
+                            uint32_t q[12], g16[3];
 #pragma unroll
                             for (int t = 0; t < 12; t++) q[t] = buf_u32(w + 4u * t);
 #pragma unroll
-                            for (int u = 0; u < 3; u++) {
-                                const uint32_t g16 = kvq_flags16(good_flags(q[4 * u], addk), good_flags(q[4 * u + 1], addk),
-                                                                 good_flags(q[4 * u + 2], addk), good_flags(q[4 * u + 3], addk));
-                                const int shu = sh + 16 * u;
-                                m |= shu >= 0 ? ((uint64_t)g16 << shu) : ((uint64_t)g16 >> (-shu));
-                            }
+                            for (int u = 0; u < 3; u++)
+                                g16[u] = kvq_flags16(good_flags(q[4 * u], addk), good_flags(q[4 * u + 1], addk),
+                                                     good_flags(q[4 * u + 2], addk), good_flags(q[4 * u + 3], addk));
+                            // 48 flag bits side by side, then one shift drops the bytes in front of the slice
+                            m = (((uint64_t)g16[2] << 32) | (uint64_t)(g16[0] | (g16[1] << 16))) >> lead;
                             w += 48u; sh += 48;
                         }
                         if (more)
@@ -740,23 +747,26 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                             const uint32_t g16 = kvq_flags16(good_flags(q[0], addk), good_flags(q[1], addk), good_flags(q[2], addk), good_flags(q[3], addk));
                             m |= sh >= 0 ? ((uint64_t)g16 << sh) : ((uint64_t)g16 >> (-sh));
                         }
-                        const uint64_t nmask = n < 64 ? (1ull << n) - 1ull : ~0ull;
+                        const uint64_t nmask = (!more || n < 64) ? (1ull << n) - 1ull : ~0ull;      // (one round of twelve dwords: n <= 45)
                         m &= nmask;
                         Seg sub; sub.beg = c0; sub.len = n;
                         int bl, bs;
                         uint64_t zz = ~m & nmask;                          // the bad bytes of the slice
                         if (!__any(__popcll(zz) > 4) && !(dbg & 4u)) {
                             // the usual case, few bad bytes in any lane's slice: walk them (runs = the gaps between them)
-                            int prev = 0, first = n; bl = 0; bs = 0;
-                            while (__any(zz != 0ull)) {
-                                if (zz) {
-                                    const int p = __ffsll((long long)zz) - 1; zz &= zz - 1ull;
-                                    if (first == n) first = p;
-                                    if (p - prev > bl) { bl = p - prev; bs = prev; }
-                                    prev = p + 1;
-                                }
-                            }
-                            if (n - prev > bl) { bl = n - prev; bs = prev; }
+                            // (branch-free: a lane that has run out of bad bytes sees "one at n", which closes its last run)
+                            int prev = 0, first = n, p; bl = 0; bs = 0;
+                            do {
+                                const uint32_t plo = (uint32_t)(__ffs((int)(uint32_t)zz) - 1), ph = (uint32_t)(__ffs((int)(uint32_t)(zz >> 32)) - 1);
+                                const uint32_t phi = ph > 0xFFFFFFDFu ? 0xFFFFFFFFu : ph + 32u;
+                                uint32_t pm = plo < phi ? plo : phi; if (pm > (uint32_t)n) pm = (uint32_t)n;
+                                p = (int)pm;
+                                zz &= zz - 1ull;
+                                first = first < p ? first : p;
+                                const int gap = p - prev;
+                                if (gap > bl) { bl = gap; bs = prev; }
+                                prev = p < n ? p + 1 : prev;
+                            } while (__any(p < n));
                             sub.pre = first; sub.suf = n - prev;
                         } else {
                             const uint64_t inv = ~m;
@@ -781,18 +791,18 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 // ordered tree merge over the G lanes of the read
                 if (G == 4u) {
                     // the common group width: neighbours inside a quad, by DPP (no LDS traffic)
-#define KVQ_QUAD(v, ctl) __builtin_amdgcn_update_dpp(0, (v), (ctl), 0xf, 0xf, false)
+#define KVQ_QUAD(v, ctl) __builtin_amdgcn_update_dpp(0, (v), (ctl), 0xf, 0xf, true)       // (every lane has a source: no "old" value to set up)
                     {
                         Seg B;                                                       // lane ^ 1: quad_perm [1,0,3,2]
                         B.len = KVQ_QUAD(sg.len, 0xB1); B.pre = KVQ_QUAD(sg.pre, 0xB1); B.suf = KVQ_QUAD(sg.suf, 0xB1);
                         B.best = KVQ_QUAD(sg.best, 0xB1); B.bstart = KVQ_QUAD(sg.bstart, 0xB1); B.beg = 0;
-                        if ((gl & 1u) == 0) sg = seg_merge(sg, B);
+                        sg = seg_merge(sg, B);            // (every lane merges -- only what lanes 0 and 2 of the quad make of it is used)
                     }
                     {
                         Seg B;                                                       // lane ^ 2: quad_perm [2,3,0,1]
                         B.len = KVQ_QUAD(sg.len, 0x4E); B.pre = KVQ_QUAD(sg.pre, 0x4E); B.suf = KVQ_QUAD(sg.suf, 0x4E);
                         B.best = KVQ_QUAD(sg.best, 0x4E); B.bstart = KVQ_QUAD(sg.bstart, 0x4E); B.beg = 0;
-                        if ((gl & 2u) == 0) sg = seg_merge(sg, B);
+                        sg = seg_merge(sg, B);            // (... lane 0)
                     }
                     rl = KVQ_QUAD(sg.best, 0x00);                                   // lane 0 of the quad: quad_perm [0,0,0,0]
                     roff = sread + (uint32_t)KVQ_QUAD(sg.bstart, 0x00);              // 1070
@@ -835,7 +845,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 if (mine) {
                     const int NPe = (rl - SK) / SS + 1;
                     const int per = (NPe + (int)G - 1) >> lg;
-                    e0 = (int)gl * per; if (e0 > NPe) e0 = NPe;
+                    e0 = (int)mul_u24(gl, (uint32_t)per); if (e0 > NPe) e0 = NPe;
                     e1 = e0 + per; if (e1 > NPe) e1 = NPe;
                 }
                 const int me_ = P.maxerrors;
