@@ -219,15 +219,22 @@ def main():
     }
     # HBM bytes per launch of the dominant kernel from the PMC passes of this same command
     # (profiles/, collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes)
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')) as f:
-            pmc = json.load(f)
+    # -- the newest round's file that matches this workload
+    import glob
+    import re
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_traffic.json')),
+                   key=lambda q: int(re.search(r'round(\d+)_', os.path.basename(q)).group(1)), reverse=True)
+    for path in cands:
+        try:
+            with open(path) as f:
+                pmc = json.load(f)
+        except (IOError, ValueError):
+            continue
         if (pmc.get('reads_per_gpu') == n and pmc.get('kernel') == out['roofline']['kernel'] and
                 pmc.get('launches_per_step') == out['roofline']['launches_per_step']):
             out['roofline']['traffic'] = pmc['hbm_bytes_per_launch']
-            out['roofline']['traffic_source'] = 'profiles/round1_pmc_traffic.json'
-    except (IOError, ValueError):
-        pass
+            out['roofline']['traffic_source'] = 'profiles/' + os.path.basename(path)
+            break
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(g, seqs, cfg, L, rb, args.cpu_seconds)
     print(json.dumps(out))

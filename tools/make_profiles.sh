@@ -1,0 +1,49 @@
+#!/bin/bash
+# Regenerates the measurement artifacts under profiles/ on an MI355X box (run through gpurun from the
+# repo root: `gpurun --timeout 1200 -- 'bash tools/make_profiles.sh round1'`).  Everything is written
+# under gpurun_out/<tag>/ ; copy what is to be kept into profiles/ afterwards (the script prints the cp lines).
+# PMC passes are separate runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes.
+set -u
+TAG=${1:-round1}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py"
+step() { echo "== $1" >> $O/progress.txt; }
+
+step bench;  cd $R && timeout -k 10 400 python3 bench.py > $O/bench_n1.json 2> $O/bench.err; cd /tmp
+step stats;  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 5 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
+step fetch;  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
+step write;  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
+step sq1;    timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq1 -- $B --steps 2 --warmup 1 --no-cpu-baseline > $O/sq1.log 2>&1
+step sq2;    timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/sq2 -- $B --steps 2 --warmup 1 --no-cpu-baseline > $O/sq2.log 2>&1
+cd $R
+python3 tools/pmc_traffic.py $O/fetch $O/write 10000000 325 > $O/pmc_traffic.json
+python3 tools/pmc_sum.py $O/sq1 > $O/pmc_sq_counters.txt; python3 tools/pmc_sum.py $O/sq2 >> $O/pmc_sq_counters.txt
+python3 tools/trace_step.py $O/stats 1 > $O/step_timeline.txt
+cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/rocprofv3_kernel_stats.csv 2>/dev/null
+step stamps; KVQ_DBG=16 timeout -k 10 200 python3 tools/phase_stamps.py > $O/phase_stamps.txt 2>&1
+step hosttimes; timeout -k 10 200 python3 tools/step_host_times.py > $O/step_host_times.txt 2>&1
+step phases
+for d in 0 1 2 32; do
+  ( cd /tmp; KVQ_DBG=$d timeout -k 10 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/ph$d -- $B --reads 5000000 --steps 2 --warmup 1 --no-cpu-baseline > $O/ph$d.log 2>&1 )
+  echo "== KVQ_DBG=$d (0: whole kernel, 1: no verify, 2: no filter and verify, 32: front end only); 5 M reads per launch" >> $O/pmc_phases.txt
+  python3 tools/pmc_sum.py $O/ph$d >> $O/pmc_phases.txt
+done
+step configs
+: > $O/other_configs.txt
+for args in "--reads 1000000" "--reads 40000000" "--readlen 300 --table MTBC+barcodes" "--table-scale 8 --reads 4000000" "--table-scale 32 --reads 4000000"; do
+  timeout -k 10 300 python3 bench.py $args --no-cpu-baseline --steps 5 > $O/cfg.json 2> $O/cfg.err
+  python3 - "$args" $O/cfg.json >> $O/other_configs.txt <<'PY'
+import json, sys
+d = json.load(open(sys.argv[2])); r = d['roofline']
+print('%-44s step %.3f ms  kernel %.3f ms/launch (%d launch/step, %.3f GB)  roofline %.4f  %.3f G reads/s' % (
+    sys.argv[1], d['ms_per_step'], r['avg_launch_ms'], r['launches_per_step'], r['algorithmic_bytes_per_launch'] / 1e9, r['frac'], d['value'] / 1e9))
+PY
+done
+step done
+for f in bench_n1.json rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt; do
+  echo "cp gpurun_out/$TAG/$f profiles/${TAG}_$f"
+done
+cat $O/bench_n1.json
