@@ -451,15 +451,23 @@ __device__ __forceinline__ void verify_item(const HotParams &P, const SeededLds 
     emit_cold(P.cold, hitC, fpos, s, sposC, lenC, rl, keyC);
 }
 
-// 16 bytes of batch text at the 16-aligned offset gp, zeros at and behind the vector that holds
-// byte hi - 1: a raw buffer load whose range check replaces the branch (no exec masking, so the
-// loads of a tile go out back to back).  The batch buffer is padded to a multiple of 16.
-__device__ __forceinline__ uint4 text_load16(const uint8_t *data, uint32_t gp, uint32_t hi)
+// The tile's text is fetched with raw buffer loads whose range check replaces the branch on "behind
+// the end of the chunk" (no exec masking, so the loads of a tile go out back to back; beyond the
+// descriptor's range a load returns zeros).  The batch buffer is padded to a multiple of 16.
+// the five vectors of a thread's scan block, for the tile whose text is [lo, hi) of the batch (lo a
+// multiple of 16): the buffer descriptor starts at the tile, so the per-thread offset `vo` is the
+// same for every tile (no address arithmetic on the vector unit) and the 16 r come as immediates;
+// a thread that has no block (thread 0) passes an offset beyond any tile and gets zeros
+#define ST_NO_BLOCK 0x7FFFFF00u
+__device__ __forceinline__ void tile_load80(const uint8_t *data, uint32_t lo, uint32_t hi, uint32_t vo, uint4 (&pre)[ST_ROUNDS])
 {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)data, 0, (int)((hi + 15u) & ~15u), 0x00020000);
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gp, 0, 0);
-    return make_uint4(v.x, v.y, v.z, v.w);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(data + lo), 0, (int)(((hi + 15u) & ~15u) - lo), 0x00020000);
+#pragma unroll
+    for (int r = 0; r < (int)ST_ROUNDS; r++) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo + 16u * (uint32_t)r), 0, 0);
+        pre[r] = make_uint4(v.x, v.y, v.z, v.w);
+    }
 }
 
 
@@ -512,10 +520,10 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
     uint4 pre[ST_ROUNDS];
     const uint32_t blk = (uint32_t)tid * ST_BLK;                           // the block's place in buf
     const uint32_t toff = blk - ST_PRE;                                    // ... and in the tile's text (tid >= 1)
+    const uint32_t vo = tid ? toff : ST_NO_BLOCK;                          // the block's place in any tile's text
     if (blockIdx.x < ntiles) {
         const TileGeo J = tile_geo(blockIdx.x, tiles, tile_bytes);
-#pragma unroll
-        for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? J.load_lo + toff + 16u * r : ~15u, J.load_hi);
+        tile_load80(data, J.load_lo, J.load_hi, vo, pre);
     }
     // Tiles are handed out by a counter (*tile_ctr starts at gridDim.x: tiles 0 .. gridDim.x - 1 are the
     // workgroups' first ones): the two workgroups of a CU do not run at the same pace (the older one wins
@@ -584,8 +592,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
         }
         if (gn < ntiles) {
             const TileGeo N = tile_geo(gn, tiles, tile_bytes);
-#pragma unroll
-            for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = text_load16(data, tid ? N.load_lo + toff + 16u * r : ~15u, N.load_hi);
+            tile_load80(data, N.load_lo, N.load_hi, vo, pre);
         }
         // the block's 80 flag bits in three words (all that crosses the barrier)
         static_assert(ST_BLK == 80u, "five vectors per block");
