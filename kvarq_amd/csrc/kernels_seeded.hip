@@ -179,7 +179,7 @@ struct SeededLds {
     uint16_t nl[ST_NLCAP];               // offsets into buf of every '\n', ascending
     uint8_t  bmA[8192], bmL[8192];       // one bit per 8-mer code: an anchor block of some sequence / anywhere in some sequence
     uint32_t hist[KVQ_RL_BINS / 2];      // read-length histogram, two 16-bit bins per word, flushed every ST_HIST_TILES tiles
-    uint2    q1[ST_QCAP];                // candidate: x = rec | pos << 16, y = code | kind << 16
+    uint2    q1[ST_QCAP];                // candidate: x = rec | pos << 16, y = offset of its 8-mer in buf | kind << 16
     uint32_t q2[ST_Q2CAP];               // work item: candidate << 22 | index entry
     uint32_t rinfo[ST_RCAP];             // read offset in buf | rl << 16
     __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];   // newlines per wave
@@ -956,11 +956,11 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                         uint32_t idx = qn + inc - c;
                         while (hA) {
                             const int j = __ffs((int)hA) - 1; hA &= hA - 1u;
-                            if (idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)(SS * (ee + j)) << 16), 0u);   // beyond the cap: dropped, the stretch is redone in halves
+                            if (idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)(SS * (ee + j)) << 16), roff + (uint32_t)(SS * (ee + j)));   // beyond the cap: dropped, the stretch is redone in halves
                             idx++;
                         }
-                        if (hh) { if (idx < ST_QW) q1[idx] = make_uint2(k | ((gl * SK) << 16), 1u << 16); idx++; }
-                        if (th && idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)(rl - ((int)gl + 1) * SK) << 16), 1u << 16);
+                        if (hh) { if (idx < ST_QW) q1[idx] = make_uint2(k | ((gl * SK) << 16), (1u << 16) | (roff + gl * SK)); idx++; }
+                        if (th && idx < ST_QW) { const uint32_t pt = (uint32_t)(rl - ((int)gl + 1) * SK); q1[idx] = make_uint2(k | (pt << 16), (1u << 16) | (roff + pt)); }
                         qn += tot;
                     }
                 }
@@ -974,7 +974,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                         const uint64_t mm = __ballot(hit);
                         if (mm) {
                             const uint32_t idx = qn + (uint32_t)__popcll(mm & kvq_lanemask_lt());
-                            if (hit && idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)pp << 16), 1u << 16);
+                            if (hit && idx < ST_QW) q1[idx] = make_uint2(k | ((uint32_t)pp << 16), (1u << 16) | (roff + (uint32_t)pp));
                             qn += (uint32_t)__popcll(mm);
                         }
                     }
@@ -990,7 +990,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                     uint32_t e0 = 0, ne = 0;
                     if (qi < qn_ok) {
                         const uint2 cd = q1[qi];
-                        const uint32_t code = lds_code8(S, (S.rinfo[cd.x & 0xFFFFu] & 0xFFFFu) + (cd.x >> 16));
+                        const uint32_t code = lds_code8(S, cd.y & 0xFFFFu);            // (the 8-mer's place came with the candidate: one LDS round trip less)
                         const uint32_t *st = (cd.y >> 16) ? X.start_all : X.start_anc;
                         e0 = st[code]; ne = st[code + 1u] - e0;
                     }
