@@ -926,22 +926,27 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                         for (int t = 0; t < 5; t++) W[t] = buf_u32(pkb + 4u * (wi + (uint32_t)t));
                         const uint32_t R0 = __builtin_amdgcn_alignbit(W[1], W[0], bo), R1 = __builtin_amdgcn_alignbit(W[2], W[1], bo),
                                        R2 = __builtin_amdgcn_alignbit(W[3], W[2], bo), R3 = __builtin_amdgcn_alignbit(W[4], W[3], bo);
-                        // five instructions and a byte from LDS per lookup: window, byte index, bit index, bit, pile up;
-                        // twelve bitmap bytes travel together (left alone the compiler waits for each)
+                        // the same stream half a word on: a 16-bit code that starts in the upper half of R[i] lies whole in H[i]
+                        const uint32_t H0 = __builtin_amdgcn_alignbit(R1, R0, 16), H1 = __builtin_amdgcn_alignbit(R2, R1, 16),
+                                       H2 = __builtin_amdgcn_alignbit(R3, R2, 16);
+                        // four instructions and a byte from LDS per lookup: byte index and bit index straight out of
+                        // the word that holds the code (v_bfe), bit, pile up; twelve bitmap bytes travel together
+                        // (left alone the compiler waits for each)
                         constexpr int NB = 12;
 #pragma unroll
                         for (int j0 = 0; j0 < NR; j0 += NB) {
-                            uint32_t win[NB], bb[NB];
+                            uint32_t bi[NB], bb[NB];
 #pragma unroll
                             for (int u = 0; u < NB; u++) {
-                                const int b = 2 * SS * (j0 + u), wj = b >> 5;
-                                const uint32_t lo = wj == 0 ? R0 : wj == 1 ? R1 : R2, hi = wj == 0 ? R1 : wj == 1 ? R2 : R3;
-                                win[u] = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(b & 31));        // the code is its low 16 bits
-                                bb[u] = lds_byte_at(KVQ_LDS_BMA + ((win[u] >> 3) & 0x1FFFu));
+                                const int b = 2 * SS * (j0 + u), wj = b >> 5, o = b & 31;
+                                const uint32_t word = o <= 16 ? (wj == 0 ? R0 : wj == 1 ? R1 : R2) : (wj == 0 ? H0 : wj == 1 ? H1 : H2);
+                                const uint32_t off = (uint32_t)(o <= 16 ? o : o - 16);                 // the code is bits off .. off + 15 of word
+                                bi[u] = __builtin_amdgcn_ubfe(word, off, 3u);
+                                bb[u] = lds_byte_at(KVQ_LDS_BMA + __builtin_amdgcn_ubfe(word, off + 3u, 13u));
                             }
                             asm volatile("" ::: "memory");
 #pragma unroll
-                            for (int u = 0; u < NB; u++) hA |= __builtin_amdgcn_ubfe(bb[u], win[u] & 7u, 1u) << (j0 + u);
+                            for (int u = 0; u < NB; u++) hA |= __builtin_amdgcn_ubfe(bb[u], bi[u], 1u) << (j0 + u);
                         }
                     }
                     const int nv = act ? (e1 - ee < NR ? e1 - ee : NR) : 0;
