@@ -34,6 +34,11 @@
 #include <algorithm>
 #include <string.h>
 
+#ifdef KVQ_NO_PRIO
+#define KVQ_SETPRIO(n) ((void)0)
+#else
+#define KVQ_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
 #define SK 8                       // seed length
 #define ST_TILE 36640u             // bytes a tile owns at the full look-ahead: 458 scan blocks of 80 bytes (tile + look-ahead = 510 blocks)
 #define ST_OV 4160u                // look-ahead for the tile's last record (52 blocks)
@@ -495,11 +500,15 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
     int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = rfl((uint32_t)tid >> 6);
     if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t *)lds_raw) != 0u) __builtin_trap();   // lds_byte_at
-    // the issue arbiter prefers the older wave of a SIMD, so waves 4..7 (the second wave of the
-    // workgroup on each SIMD) used to reach the tile-end barrier ~2 k cycles behind waves 0..3, which
-    // then waited there; a higher priority for the younger four during the trim evens the arrival
-    // out (during all of P3/P4 it overshoots).  KVQ_DBG bit 6 switches it off.
-    const bool younger = wave >= 4u && ((dbg >> 6) & 1u) == 0u;
+    // Wave priorities (s_setprio; building with -DKVQ_NO_PRIO leaves them out).  A wave's priority rises as it gets
+    // on with its tile: 0 in the front end (fetch, flags, newline list, P2 -- the part that is made of
+    // barriers anyway), 1 in the trim, 2 in the seed filter, 3 while it verifies (a chain of dependent
+    // table loads: the sooner they are issued the better they hide), back to 0 for the tile-end barrier.
+    // "Nearest to the end of its tile goes first" is worth 5 % over equal priorities.  The issue arbiter
+    // also prefers the older wave of a SIMD, so waves 4..7 (the second wave of the workgroup on each
+    // SIMD) used to reach the tile-end barrier ~2 k cycles behind waves 0..3, which then waited there:
+    // they run the trim one step higher.
+    const bool younger = wave >= 4u;
     HotParams P;
     P.cold = Pg; P.tab = (GlbBytes)Pg->tab; P.maxerrors = Pg->maxerrors; P.minoverlap = Pg->minoverlap;
     P.minreadlength = Pg->minreadlength; P.amin = Pg->amin;
@@ -684,7 +693,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
 
         if (dbg & 32u) nrec = 0;                                     // diagnostic: front end only
         STAMP(3);
-        if (younger) __builtin_amdgcn_s_setprio(2);
+        if (younger) KVQ_SETPRIO(2); else KVQ_SETPRIO(1);
         unsigned long long wave_t3 = 0;
         if constexpr (STAMPS) wave_t3 = __builtin_amdgcn_s_memtime();
         // ---- P3 / P4 passes: reads -> candidates, then candidates -> hits ----
@@ -831,7 +840,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                 }
             }
             STAMP(4);
-            if (younger) __builtin_amdgcn_s_setprio(0);
+            KVQ_SETPRIO(2);
             // filter + verify, wave by wave: a wave's reads (64/G of them), its candidates and its work
             // items are its own (queue segments wave * ST_QW / wave * ST_Q2W, counts in scalar
             // registers), so nothing between here and the end of the tile waits for another wave.
@@ -985,6 +994,7 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                     }
                 }
                 STAMP(5);
+                KVQ_SETPRIO(3);
 
                 // ---- P4a: one candidate per lane: index range -> (candidate, entry) work items ----
                 const bool over1 = qn > ST_QW;                            // candidates were dropped
@@ -1025,8 +1035,10 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
                         verify_item(P, S, active, rec, p, kind, en, tile_fpos, SS);
                     }
                 }
+                KVQ_SETPRIO(2);
                 sub += step;
             }
+            KVQ_SETPRIO(0);
             STAMP(6);
         }
         if constexpr (STAMPS) wave_p34 += __builtin_amdgcn_s_memtime() - wave_t3;
