@@ -15,6 +15,10 @@ and the counter arrays are summed with one RCCL all-reduce per step.
     python bench.py                                   # N=1, 10 M reads
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
 
+Before the W warmup steps the setup runs `--preheat` (30) untimed scans of the same batch: in a
+fresh process the GPU clocks take about ten steps (20 ms) to settle, and without it the first timed
+steps of a short run measure the ramp (1.63 ms per launch instead of 1.58); `--preheat 0` switches it off.
+
 Prints ONE JSON line on rank 0 (contract in the task description): value =
 whole-job reads/s, roofline = algorithmic bytes (2L+25 per record) of the
 dominant kernel / its HIP-event time vs 8 TB/s HBM peak, cpu_baseline = the
@@ -67,6 +71,7 @@ def main():
     ap.add_argument('--table-scale', type=int, default=1)
     ap.add_argument('--exhaustive', action='store_true', help='force the exhaustive kernel for every sequence')
     ap.add_argument('--batch-bytes', type=int, default=(1 << 32) - (1 << 20), help='largest batch handed to kvq_scan_device')
+    ap.add_argument('--preheat', type=int, default=30, help='untimed scans before the warmup steps (the GPU clocks take ~10 steps = 20 ms to settle in a fresh process)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of the CPU baseline sample')
     args = ap.parse_args()
@@ -163,6 +168,8 @@ def main():
             torch.cuda.synchronize()
 
     r = None
+    for _ in range(max(0, args.preheat)):        # part of the setup: brings the clocks up, not counted as steps
+        r = step()
     for _ in range(args.warmup):
         r = step()
     sync()
@@ -209,7 +216,8 @@ def main():
                    'parallelism': 'read-shard x%d, all-reduce of counter arrays' % world if world > 1 else 'single GPU',
                    'kernel_path': 'exhaustive' if args.exhaustive or not any(table.seeded) else
                                   'seed-filter k=%d (%d of %d sequences)' % (table.seed_k, sum(table.seeded), table.nseq),
-                   'hits_per_step': total_hits, 'records_per_step': total_records},
+                   'hits_per_step': total_hits, 'records_per_step': total_records,
+                   'preheat_steps': max(0, args.preheat)},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                      'kernel': 'kvq_scan_seeded' if any(table.seeded) and not args.exhaustive else 'kvq_match_all',

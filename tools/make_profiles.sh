@@ -10,14 +10,15 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
+BP="$B --preheat 0"          # counter passes: every launch is counted, no need to heat the clocks
 step() { echo "== $1" >> $O/progress.txt; }
 
 step bench;  cd $R && timeout -k 10 400 python3 bench.py > $O/bench_n1.json 2> $O/bench.err; cd /tmp
 step stats;  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 5 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
-step fetch;  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
-step write;  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
-step sq1;    timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq1 -- $B --steps 2 --warmup 1 --no-cpu-baseline > $O/sq1.log 2>&1
-step sq2;    timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/sq2 -- $B --steps 2 --warmup 1 --no-cpu-baseline > $O/sq2.log 2>&1
+step fetch;  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
+step write;  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
+step sq1;    timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq1 -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/sq1.log 2>&1
+step sq2;    timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/sq2 -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/sq2.log 2>&1
 cd $R
 python3 tools/pmc_traffic.py $O/fetch $O/write 10000000 325 > $O/pmc_traffic.json
 python3 tools/pmc_sum.py $O/sq1 > $O/pmc_sq_counters.txt; python3 tools/pmc_sum.py $O/sq2 >> $O/pmc_sq_counters.txt
@@ -27,7 +28,7 @@ step stamps; KVQ_DBG=16 timeout -k 10 200 python3 tools/phase_stamps.py > $O/pha
 step hosttimes; timeout -k 10 200 python3 tools/step_host_times.py > $O/step_host_times.txt 2>&1
 step phases
 for d in 0 1 2 32; do
-  ( cd /tmp; KVQ_DBG=$d timeout -k 10 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/ph$d -- $B --reads 5000000 --steps 2 --warmup 1 --no-cpu-baseline > $O/ph$d.log 2>&1 )
+  ( cd /tmp; KVQ_DBG=$d timeout -k 10 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/ph$d -- $BP --reads 5000000 --steps 2 --warmup 1 --no-cpu-baseline > $O/ph$d.log 2>&1 )
   echo "== KVQ_DBG=$d (0: whole kernel, 1: no verify, 2: no filter and verify, 32: front end only); 5 M reads per launch" >> $O/pmc_phases.txt
   python3 tools/pmc_sum.py $O/ph$d >> $O/pmc_phases.txt
 done
