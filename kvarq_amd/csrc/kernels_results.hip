@@ -46,7 +46,7 @@ static KvqResultLayout kvq_result_layout(uint64_t n, uint64_t blob_bytes)
 // a comparison sort over the whole array.  A bucket with more than KVQ_BUCKET_MAX hits (hits
 // crowded into a corner of the stream) raises a flag and the host orders the scan with the merge
 // sort below instead.
-#define KVQ_BUCKET_MAX 32u
+#define KVQ_BUCKET_MAX 64u
 
 struct KvqBucketPlan { int64_t lo; uint32_t shift, nb; };       // bucket = (file_pos - lo) >> shift, nb buckets
 
@@ -67,44 +67,66 @@ kvq_bucket_scatter(const KvqHit *__restrict__ arena, uint32_t n, KvqBucketPlan B
     idx[start[b] + atomicAdd(&fill[b], 1u)] = h;
 }
 
-// one thread per bucket: insertion sort of its (few) hit numbers
+// one thread per bucket: its (few) hit numbers put in order.  Up to eight hits: sorting network in
+// registers.  Nine to KVQ_BUCKET_MAX (a read on a locus that many templates share): the wave takes
+// such buckets one at a time, lane i holds hit i and counts the hits in front of it (no dependent
+// loads: a serial insertion sort of 20 hits used to set the time of the whole kernel).
 __global__ void __launch_bounds__(256)
 kvq_bucket_sort(const KvqHit *__restrict__ arena, KvqBucketPlan B, const uint32_t *__restrict__ start, uint32_t *__restrict__ idx,
                 uint32_t *__restrict__ crowded)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B.nb) return;
-    const uint32_t s0 = start[b], m = start[b + 1] - s0;
-    if (m < 2u) return;
-    if (m > KVQ_BUCKET_MAX) { *crowded = 1u; return; }
-    const KvqHitBefore before;
-    if (m <= 8u) {
-        // the usual bucket: its hits are fetched side by side (not one per comparison) and sorted in registers
-        uint32_t ix[8]; KvqHit h[8];
+    const int lane = kvq_lane();
+    uint32_t s0 = 0, m = 0;
+    if (b < B.nb) { s0 = start[b]; m = start[b + 1] - s0; }
+    if (m > KVQ_BUCKET_MAX) { *crowded = 1u; m = 0; }
+    if (m >= 2u && m <= 8u) {
+        // the usual bucket: the sort keys of its hits (file_pos; seq_nr, class | ordinal: 16 of a hit's 32
+        // bytes) are fetched side by side and sorted in registers together with the hit numbers
+        uint32_t ix[8]; long long k1[8]; unsigned long long k2[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) ix[i] = (uint32_t)i < m ? idx[s0 + i] : 0u;
 #pragma unroll
-        for (int i = 0; i < 8; i++) if ((uint32_t)i < m) h[i] = arena[ix[i]];
-        // odd-even transposition network over the first m of 8 slots (no dynamic register indexing)
+        for (int i = 0; i < 8; i++) {
+            const KvqHit *h = &arena[ix[i]];
+            k1[i] = (uint32_t)i < m ? h->fpos : 0x7FFFFFFFFFFFFFFFll;                      // (empty slots sort last)
+            k2[i] = (uint32_t)i < m ? ((unsigned long long)(uint32_t)h->seq_nr << 32) | h->key : ~0ull;
+        }
+        // odd-even transposition network over the 8 slots (no dynamic register indexing)
 #pragma unroll
         for (int round = 0; round < 8; round++) {
 #pragma unroll
             for (int i = round & 1; i + 1 < 8; i += 2) {
-                if ((uint32_t)(i + 1) < m && before(h[i + 1], h[i])) {
-                    const KvqHit th = h[i]; h[i] = h[i + 1]; h[i + 1] = th;
-                    const uint32_t ti = ix[i]; ix[i] = ix[i + 1]; ix[i + 1] = ti;
-                }
+                const bool swap = k1[i + 1] < k1[i] || (k1[i + 1] == k1[i] && k2[i + 1] < k2[i]);
+                const long long a1 = swap ? k1[i + 1] : k1[i], b1 = swap ? k1[i] : k1[i + 1];
+                const unsigned long long a2 = swap ? k2[i + 1] : k2[i], b2 = swap ? k2[i] : k2[i + 1];
+                const uint32_t ai = swap ? ix[i + 1] : ix[i], bi = swap ? ix[i] : ix[i + 1];
+                k1[i] = a1; k1[i + 1] = b1; k2[i] = a2; k2[i + 1] = b2; ix[i] = ai; ix[i + 1] = bi;
             }
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) if ((uint32_t)i < m) idx[s0 + i] = ix[i];
-        return;
     }
-    for (uint32_t i = 1; i < m; i++) {
-        const uint32_t x = idx[s0 + i]; const KvqHit hx = arena[x];
-        uint32_t j = i;
-        while (j > 0u && before(hx, arena[idx[s0 + j - 1u]])) { idx[s0 + j] = idx[s0 + j - 1u]; j--; }
-        idx[s0 + j] = x;
+    // the wave's larger buckets, all 64 lanes on one at a time (every lane of the wave gets here)
+    static_assert(KVQ_BUCKET_MAX <= 64u, "one lane per hit");
+    unsigned long long todo = __ballot(m > 8u);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
+        const uint32_t bs0 = (uint32_t)__shfl((int)s0, src, 64), bm = (uint32_t)__shfl((int)m, src, 64);
+        uint32_t mine = 0; long long a1 = 0x7FFFFFFFFFFFFFFFll; unsigned long long a2 = ~0ull;
+        if ((uint32_t)lane < bm) {
+            mine = idx[bs0 + (uint32_t)lane];
+            const KvqHit *h = &arena[mine];
+            a1 = h->fpos; a2 = ((unsigned long long)(uint32_t)h->seq_nr << 32) | h->key;
+        }
+        uint32_t rank = 0;                                       // hits that come before this lane's
+        for (uint32_t j = 0; j < bm; j++) {
+            const long long b1 = ((long long)__shfl((int)(a1 >> 32), (int)j, 64) << 32) | (uint32_t)__shfl((int)a1, (int)j, 64);
+            const unsigned long long b2 = ((unsigned long long)(uint32_t)__shfl((int)(a2 >> 32), (int)j, 64) << 32) | (uint32_t)__shfl((int)a2, (int)j, 64);
+            rank += (b1 < a1 || (b1 == a1 && (b2 < a2 || (b2 == a2 && j < (uint32_t)lane)))) ? 1u : 0u;
+        }
+        // (every lane has fetched its hit number before any lane stores: one wave, in step)
+        if ((uint32_t)lane < bm) idx[bs0 + rank] = mine;
     }
 }
 

@@ -228,6 +228,28 @@ def test_many_hits_per_read_come_back_in_reference_order():
     s.close(); t.close(); d.free()
 
 
+@pytest.mark.parametrize('k', [4, 7, 12, 20])
+def test_a_few_dozen_hits_per_read_are_ranked_by_the_wave(k):
+    """9 to 64 hits on one file position: the bucket ordering ranks them with one lane per hit
+    (kernels_results.hip): 10, 19, 34 and 58 hits per read"""
+    read = 'ACG' * k + 'T'
+    data = np.frombuffer(b''.join(cases.rec('r%d' % i, read, 'I' * len(read)) for i in range(400)), dtype=np.uint8)
+    seqs = [b'ACG', b'CGA', b'GAC']
+    cfg = dict(cases.DEFAULTS, minreadlength=10)
+    o = O.scan_memory(data, seqs, fold=True, **dict(cfg, nthreads=4))
+    per_read = len(o['hits']) // 400
+    assert 8 < per_read <= 64
+    t = scan.Table(seqs, **cfg)
+    s = scan.Scanner(t)
+    d = scan.DeviceBuffer(data.nbytes)
+    d.upload(data)
+    s.scan_device(d.ptr, data.nbytes, scan.chunk_offsets(data))
+    r = s.finish()
+    assert tuple(r['hits']) == tuple(o['hits']) and r['hitseqs'] == o['hitseqs']
+    assert r['coverage'].tolist() == o['coverage']
+    s.close(); t.close(); d.free()
+
+
 def test_concurrent_findseqs_is_refused_and_stop_works(tmp_path):
     import threading, time
     p = tmp_path / 'big.fastq'
