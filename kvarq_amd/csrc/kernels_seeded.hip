@@ -41,6 +41,7 @@
 #endif
 #define SK 8                       // seed length
 #define ST_TILE 36640u             // bytes a tile owns at the full look-ahead: 458 scan blocks of 80 bytes (tile + look-ahead = 510 blocks)
+#define ST_TILE_MIN 30960u         // the least a tile owns (kvq_choose_tile cuts a tile to a whole number of lane groups)
 #define ST_OV 4160u                // look-ahead for the tile's last record (52 blocks)
 #define ST_PRE 80u                 // one (zeroed) block in front of the tile: buf[ST_PRE] = first owned byte
 #define ST_THREADS 512
@@ -1108,28 +1109,55 @@ kvq_expand_tiles(uint32_t nchunks, const uint32_t *__restrict__ chunk_off, const
     for (uint32_t g = g0; g < tile_first[c + 1]; g++) tile_tab[g] = make_uint4(a, b, g - g0, c);
 }
 
-// Bytes a tile owns (a multiple of ST_BLK, ST_TILE .. ST_TILE + ST_OV - 1040): the LDS buffer holds
+// Bytes a tile owns (a multiple of ST_BLK, ST_TILE_MIN .. ST_TILE + ST_OV - 1040): the LDS buffer holds
 // ST_TILE + ST_OV bytes, and what a tile does not own it reads a second time as the look-ahead for
 // its last record.  The look-ahead must cover the longest record; `maxline` is the longest line
 // (with its newline) among the first bytes of the scan, a record has four lines.  A later record
 // that outgrows the look-ahead sends its batch to the exhaustive kernels (and the scan back to the
 // full look-ahead), so this is a matter of speed only.
-uint32_t kvq_choose_tile(uint32_t maxline)
+// `rec_bytes` (0 = unknown) is the average record among those first bytes: the lane group of a read is
+// the widest power of two G with G * records <= 512, so a tile with a few records more than a power of
+// two p runs at half the group width (145 records of 125 bp: two lanes per read, 57 % of the lanes
+// busy, 63-byte slices); when owning p - 1 records costs less than 22 % of the tile, the tile is cut
+// to that (measured: 125 bp + 13 %, 120 bp + 6 %, 110 bp + 3 %; 105 bp, where it costs 25 %, - 2 %).
+uint32_t kvq_choose_tile(uint32_t maxline, uint32_t rec_bytes)
 {
     if (const char *e = getenv("KVQ_TILE")) { const int v = atoi(e); if (v >= 4000 && v <= (int)(ST_TILE + ST_OV - 1040u)) return (uint32_t)v / ST_BLK * ST_BLK; }
     if (maxline == 0) return ST_TILE;
     uint32_t ov = (4u * (maxline + 2u) + 160u + ST_BLK - 1u) / ST_BLK * ST_BLK;
     ov = std::max<uint32_t>(1040u, std::min<uint32_t>(ov, ST_OV));
-    return ST_TILE + ST_OV - ov;
+    uint32_t tile = ST_TILE + ST_OV - ov;
+    if (rec_bytes >= 40u) {
+        const uint32_t n_full = tile / rec_bytes + 1u;                     // records a full tile can own
+        uint32_t p = 1; while (2u * p <= n_full) p *= 2u;
+        if (p >= 16u && p <= (uint32_t)ST_THREADS && n_full > p) {
+            const uint32_t cut = (p - 1u) * rec_bytes / ST_BLK * ST_BLK;
+            if (cut >= ST_TILE_MIN && (uint64_t)cut * 100u >= (uint64_t)tile * 78u) tile = cut;
+        }
+    }
+    return tile;
+}
+uint32_t kvq_min_tile()
+{
+    if (getenv("KVQ_TILE")) return std::min<uint32_t>(ST_TILE_MIN, kvq_choose_tile(1u << 20, 0));
+    return ST_TILE_MIN;
 }
 
-// the longest line (newline included) among the first bytes of a text; an unfinished last line counts
-uint32_t kvq_longest_line(const uint8_t *text, size_t n)
+// the longest line (newline included) among the first bytes of a text (an unfinished last line counts)
+// and the average record (four lines) among them, 0 when there are fewer than four records
+void kvq_probe_text(const uint8_t *text, size_t n, uint32_t &maxline, uint32_t &rec_bytes)
 {
-    uint32_t best = 0; size_t start = 0;
+    uint32_t best = 0; size_t start = 0, lines = 0;
     for (size_t i = 0; i < n; i++)
-        if (text[i] == '\n') { best = std::max<uint32_t>(best, (uint32_t)(i + 1 - start)); start = i + 1; }
-    return std::max<uint32_t>(best, (uint32_t)(n - start));
+        if (text[i] == '\n') { best = std::max<uint32_t>(best, (uint32_t)(i + 1 - start)); start = i + 1; lines++; }
+    maxline = std::max<uint32_t>(best, (uint32_t)(n - start));
+    rec_bytes = lines >= 16 ? (uint32_t)(start * 4 / lines) : 0u;           // (start = bytes in whole lines)
+}
+uint32_t kvq_tile_for_text(const uint8_t *text, size_t n)
+{
+    uint32_t maxline, rec_bytes;
+    kvq_probe_text(text, n, maxline, rec_bytes);
+    return kvq_choose_tile(maxline, rec_bytes);
 }
 
 int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
@@ -1146,7 +1174,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         std::vector<uint8_t> head(n);
         KVQ_HIP(hipStreamSynchronize(s->stream));
         KVQ_HIP(hipMemcpy(head.data(), d_data, n, hipMemcpyDeviceToHost));
-        s->tile_bytes = kvq_choose_tile(kvq_longest_line(head.data(), n));
+        s->tile_bytes = kvq_tile_for_text(head.data(), n);
     }
     const uint32_t TILE = ix->variant ? kvq_planes_tile_bytes() : s->tile_bytes;
     uint64_t nt = 0;

@@ -117,8 +117,9 @@ void       kvq_seed_index_destroy(SeedIndex *ix);
 int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
                       const uint32_t *d_chunk_off, int64_t nchunks, int64_t fpos_base, uint32_t max_chunk_bytes);
 
-uint32_t kvq_choose_tile(uint32_t maxline);
-uint32_t kvq_longest_line(const uint8_t *text, size_t n);
+uint32_t kvq_choose_tile(uint32_t maxline, uint32_t rec_bytes);
+uint32_t kvq_min_tile();
+uint32_t kvq_tile_for_text(const uint8_t *text, size_t n);
 
 // synth.hip
 // (C ABI only)
