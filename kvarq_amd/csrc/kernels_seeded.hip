@@ -1073,24 +1073,33 @@ kvq_scan_seeded(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *_
 // one thread per chunk: replay the tile reports against the exact newline
 // count; any tile whose speculated first record is not the one the count gives
 // sets *spec_fail (the host then rescans with the exhaustive kernels)
+__host__ __device__ static inline bool kvq_tile_report_bad(uint32_t rep, bool first_tile, uint32_t seen, uint32_t total)
+{
+    const uint32_t n_owned = rep & 0xFFFFu, jn = (rep >> 16) & 0xFFu;
+    if (rep & TR_FLAG_FALLBACK) return true;
+    // the first record this tile owns starts behind its newline number `want` (tile 0: the chunk
+    // start itself) -- if the chunk goes on for at least two more lines behind that newline: the
+    // kernel wants to see the record's '+' line (P2), and a chunk that ends there has no record left
+    // (the chunk's last tile often owns nothing but the final newline of the last record)
+    const uint32_t want = first_tile ? 0u : 4u - (seen & 3u);
+    const bool expect = want <= n_owned && (first_tile || want + 2u <= total - seen);
+    return expect ? jn != want : jn != TR_NONE;
+}
+
 extern "C" __global__ void __launch_bounds__(256)
 kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_report,
                    unsigned int *__restrict__ spec_fail)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
+    uint32_t total = 0;                        // newlines of the chunk
+    for (uint32_t g = tile_first[c]; g < tile_first[c + 1]; g++) total += tile_report[g] & 0xFFFFu;
     uint32_t seen = 0;                         // newlines of the chunk in front of the tile
     bool bad = false;
     for (uint32_t g = tile_first[c]; g < tile_first[c + 1]; g++) {
         const uint32_t rep = tile_report[g];
-        const uint32_t n_owned = rep & 0xFFFFu, jn = (rep >> 16) & 0xFFu;
-        if (rep & TR_FLAG_FALLBACK) bad = true;
-        // the first record this tile owns starts behind its newline number `want`
-        // (tile 0: the chunk start itself)
-        const uint32_t want = g == tile_first[c] ? 0u : 4u - (seen & 3u);
-        if (want <= n_owned) { if (jn != want) bad = true; }
-        else if (jn != TR_NONE) bad = true;
-        seen += n_owned;
+        if (kvq_tile_report_bad(rep, g == tile_first[c], seen, total)) bad = true;
+        seen += rep & 0xFFFFu;
     }
     if (bad) atomicOr(spec_fail, 1u);
 }
@@ -1236,5 +1245,21 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                        d_first, d_report, s->cur_fail);
     KVQ_HIP(hipGetLastError());
+    if (getenv("KVQ_DBG_REPORT") && !ix->variant) {
+        // diagnostic: replay kvq_validate_tiles on the host and name the tiles it rejects
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        std::vector<uint32_t> rep((size_t)nt);
+        KVQ_HIP(hipMemcpy(rep.data(), d_report, (size_t)nt * 4, hipMemcpyDeviceToHost));
+        for (int64_t c = 0; c < nchunks; c++) {
+            uint32_t seen = 0, total = 0;
+            for (uint32_t g = first[c]; g < first[c + 1]; g++) total += rep[g] & 0xFFFFu;
+            for (uint32_t g = first[c]; g < first[c + 1]; g++) {
+                if (kvq_tile_report_bad(rep[g], g == first[c], seen, total))
+                    fprintf(stderr, "tile %u (chunk %lld [%lld, %lld), tile %u of it): report %08x n_owned %u jn %u seen %u of %u\n",
+                            g, (long long)c, (long long)co[c], (long long)co[c + 1], g - first[c], rep[g], rep[g] & 0xFFFFu, (rep[g] >> 16) & 0xFFu, seen, total);
+                seen += rep[g] & 0xFFFFu;
+            }
+        }
+    }
     return KVQ_OK;
 }

@@ -228,6 +228,43 @@ def test_many_hits_per_read_come_back_in_reference_order():
     s.close(); t.close(); d.free()
 
 
+@pytest.mark.parametrize('tile', [None, '8000', '8080', '24000'])
+def test_well_formed_files_never_fall_back_to_the_exhaustive_kernels(tile, monkeypatch):
+    """ragged records over several chunks, at several tile sizes: every tile's speculated record
+    split is accepted (a rejected one costs a rescan of the whole batch with the exhaustive
+    kernels -- the chunk's last tile, which often owns nothing but the final newline, used to be one)"""
+    import os
+    import random
+    if os.environ.get('KVQ_KERNEL') == 'planes' and tile is not None:
+        pytest.skip('KVQ_TILE sizes the tiles of the seed-filter kernel only')
+    if tile is not None:
+        monkeypatch.setenv('KVQ_TILE', tile)
+    rng = random.Random(77)
+    genome = cases.randseq(rng, 5000)
+    recs = []
+    for i in range(26000):
+        L = rng.choice([76, 100, 125, 150, 150, 151, rng.randint(40, 250)])
+        a = rng.randrange(0, len(genome) - L)
+        recs.append(cases.rec('M01:%d:%d:%d' % (i, rng.randrange(30000), rng.randrange(30000)), genome[a:a + L], 'I' * L))
+    text = b''.join(recs)
+    assert len(text) > 5 * (1 << 20)
+    data = np.frombuffer(text, dtype=np.uint8)
+    seqs = [genome[100:151].encode(), genome[2000:2051].encode(), genome[3000:3025].encode()]
+    t = scan.Table(seqs, **cases.PRODUCT)
+    res = []
+    for force in (False, True):
+        s = scan.Scanner(t)
+        s.force_exhaustive(force)
+        s.scan_host(data)
+        res.append(s.finish())
+        s.close()
+    a, b = res
+    assert a['path'] == dict(seeded=True, exhaustive=False, rescanned=False), a['path']
+    assert a['n_hits'] == b['n_hits'] > 100 and tuple(a['hits']) == tuple(b['hits']) and a['hitseqs'] == b['hitseqs']
+    assert a['counters'].tolist() == b['counters'].tolist()
+    t.close()
+
+
 @pytest.mark.parametrize('k', [4, 7, 12, 20])
 def test_a_few_dozen_hits_per_read_are_ranked_by_the_wave(k):
     """9 to 64 hits on one file position: the bucket ordering ranks them with one lane per hit
