@@ -326,7 +326,7 @@ def test_seeded_and_exhaustive_kernels_agree_and_paths_are_as_expected(tmp_path)
     # a 9 kB record that starts 36 kB into the text outgrows the look-ahead of the tile that owns it
     # (a tile and its look-ahead span 40.8 kB): that batch is redone exhaustively
     import os
-    if os.environ.get('KVQ_KERNEL') != 'planes':         # (the bit-plane kernel cuts its tiles elsewhere)
+    if os.environ.get('KVQ_KERNEL') != 'planes' and not os.environ.get('KVQ_TILE'):   # (the bit-plane kernel, or another tile size, cuts the tiles elsewhere)
         want_path['long_reads_straddle'] = dict(seeded=True, exhaustive=True, rescanned=True)
     for name, wp in want_path.items():
         case = cases.by_name()[name.replace('_straddle', '')]
