@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Per-phase cycles of the seed-filter kernel from the instrumented build (KVQ_DBG=16): in-kernel
+s_memtime stamps of wave 0, summed per phase in spare counter slots.
+
+usage: KVQ_DBG=16 python tools/phase_stamps.py
+"""
 import sys, os
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import numpy as np
