@@ -2,7 +2,8 @@
 // the FastQ text does record split, quality trim, read-length histogram and
 // matching (workhorse.c:1010-1175) for every sequence that qualifies for seeding.
 //
-// Persistent workgroups (512 threads, two per CU) walk 32000-byte tiles of the input:
+// Persistent workgroups (512 threads, two per CU) walk tiles of up to 39760 bytes of the input,
+// handed out by a counter (kvq_choose_tile sizes them, wave priorities rise through a tile):
 //   P0  every thread fetches the 80 contiguous bytes it scans (buffer loads, issued one tile
 //       ahead), writes them to LDS and takes the newline flags from the registers
 //   P1  workgroup prefix sum -> sorted newline offsets in LDS
