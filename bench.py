@@ -63,8 +63,8 @@ def analytic_chunk_offsets(n_records, rb, L):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--reads', type=int, default=10_000_000, help='records per GPU')
     ap.add_argument('--readlen', type=int, default=150)
     ap.add_argument('--table', default='MTBC', choices=['MTBC', 'MTBC+barcodes'])
