@@ -1,0 +1,741 @@
+// kvarq_amd/csrc/kernels_bp.hip -- the fused seed-filter scan on bit-planes (the default scan
+// kernel; kernels_seeded.hip's text-in-LDS kernel stays selectable with KVQ_KERNEL=v1 and shares
+// the seed index, the tile geometry, the tile reports and the launch code with this one).
+//
+// Why planes: kvq_scan_seeded keeps the tile's text in LDS (80 KB per workgroup, 117 VGPRs), which
+// caps a CU at 16 waves, and it is latency bound (profiles/round1_pmc_sq_counters.txt: waves
+// parked 48 % of their cycles, vector pipes 38 % busy).  Here every byte of the text is looked at
+// once, in the registers it was fetched into, and LDS holds three bits per byte: "score >= Amin"
+// (1 bit) and the 2-bit base code (byte >> 1) & 3.  That is 15 KB instead of 40 KB per tile, so a
+// workgroup fits 40 KB of LDS / 64 VGPRs and a CU holds four of them: 32 waves, 8 per SIMD.
+//
+//   P0  every thread turns the 80 contiguous bytes it fetched (one tile ahead, as in v1) into
+//       80 newline flags (registers), 80 good-score bits and 160 code bits (LDS)
+//   P1  workgroup prefix sum -> sorted newline offsets in LDS        (as v1)
+//   P2  first record of the tile, speculated and validated after the kernel   (as v1; the '@' / '+'
+//       bytes it looks at come from global memory: the text is not in LDS)
+//   P3  G lanes per read: quality trim = longest run of ones in a bit range of the good plane
+//       (workhorse.c:1055-1068), histogram; seed filter: the read's packed bases ARE a bit range
+//       of the code plane, each 8-mer code is one v_alignbit away
+//   P4  candidates -> (candidate, index entry) items -> first 16 bases compared as 2-bit codes
+//       (plane against a 2-bit copy of the table: equal bytes have equal codes, so this only ever
+//       rejects), survivors byte-exact against the text in global memory (1112-1174)
+#include "kvq_host.h"
+
+// a comment line in the ISA text (tools/isa_marks.py counts the instructions between two of them)
+#define KVQ_MARK(name) asm volatile("; KVQMARK " name)
+#define BP_WIN (ST_BUF + ST_BLK)   // bytes of text a tile's planes cover: 512 blocks of 80
+#define BP_QW 96                   // candidates per wave and stretch
+#define BP_Q2W 96                  // work items per wave and stretch
+#define BP_QCAP (BP_QW * ST_WAVES)
+#define BP_Q2CAP (BP_Q2W * ST_WAVES)
+
+struct BpLds {
+    uint32_t cdp[BP_WIN / 16 + 8];       // code plane: 2 bits per byte, byte o of the window in bits 2o, 2o+1
+    uint32_t gdp[BP_WIN / 32 + 8];       // good plane: 1 bit per byte (score byte >= Amin)
+    uint16_t nl[ST_NLCAP];               // window offsets of every '\n', ascending
+    uint8_t  bmA[8192];                  // one bit per 8-mer code: an anchor block of some sequence
+    uint32_t hist[KVQ_RL_BINS / 2];      // read-length histogram, two 16-bit bins per word
+    uint32_t q1[BP_QCAP];                // candidate: read (9 bits) | position in the read << 9 (12 bits) | kind << 21
+    uint32_t q2[BP_Q2CAP];               // work item: candidate << 22 | index entry
+    uint32_t rinfo[ST_RCAP];             // read offset in the window | rl << 16
+    __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];
+    uint32_t longest_p1, records, fallback, n_owned, next_tile;
+};
+static_assert(sizeof(BpLds) <= 40 * 1024, "four workgroups per CU: at most 40 KB of LDS each");
+static_assert(offsetof(BpLds, cdp) == 0, "cdp[] first");
+#define BP_LDS_GDP ((uint32_t)offsetof(BpLds, gdp))
+#define BP_LDS_BMA ((uint32_t)offsetof(BpLds, bmA))
+
+// (the kernel's only LDS object starts at LDS address 0: checked at kernel start)
+__device__ __forceinline__ uint32_t lds_u32_at(uint32_t addr)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)addr);
+}
+// 32 bits of the code plane from window byte `pos` on (16 bases) / its 8-mer code
+__device__ __forceinline__ uint32_t cdp32(uint32_t pos)
+{
+    const uint32_t a = (pos >> 2) & ~3u, sh = (pos & 15u) * 2u;
+    return __builtin_amdgcn_alignbit(lds_u32_at(a + 4u), lds_u32_at(a), sh);
+}
+__device__ __forceinline__ uint32_t cdp_code8(uint32_t pos) { return cdp32(pos) & 0xFFFFu; }
+
+// the same for the 2-bit copy of the sequence table in global memory
+typedef const __attribute__((address_space(1))) uint32_t *GlbWords;
+__device__ __forceinline__ uint32_t tab2_32(GlbWords tab2, uint32_t tpos)
+{
+    const uint32_t w = tpos >> 4, sh = (tpos & 15u) * 2u;
+    return __builtin_amdgcn_alignbit(tab2[w + 1u], tab2[w], sh);
+}
+
+// bases that differ between two words of 16 2-bit codes
+__device__ __forceinline__ int diff_codes(uint32_t x, uint32_t y)
+{
+    const uint32_t v = x ^ y;
+    return __popc((v | (v >> 1)) & 0x55555555u);
+}
+
+__device__ __forceinline__ bool seed_live_bp(GlbWords tab2, uint32_t roff, int rl, int rp, uint32_t toff, int seql, int sq)
+{
+    if (rp < 0 || rp + SK > rl || sq < 0 || sq + SK > seql) return false;
+    return cdp_code8(roff + (uint32_t)rp) == (tab2_32(tab2, toff + (uint32_t)sq) & 0xFFFFu);
+}
+
+// One work item = one (candidate, index entry) pair = one diagonal of one read against one
+// sequence (the rules of verify_item in kernels_seeded.hip; the read's bytes come from global
+// memory, `text` = address of window offset 0).  Must be called by every lane of the wave.
+__device__ __forceinline__ void verify_item_bp(const HotParams &P, const BpLds &S, GlbWords tab2, GlbBytes text, bool active,
+                                               uint32_t rec, int p, uint32_t kind, uint64_t en, int64_t tile_fpos, int stride)
+{
+    bool hitAB = false, hitC = false;
+    int s = 0, rl = 0, lenAB = 0, lenC = 0, sposAB = 0, sposC = 0; uint32_t keyAB = 0, keyC = 0;
+    int64_t fpos = 0;
+    if (active) {
+        const uint32_t ri = S.rinfo[rec];
+        const uint32_t roff = ri & 0xFFFFu; rl = (int)(ri >> 16);
+        fpos = tile_fpos + (int64_t)roff - (int64_t)ST_PRE;
+        const int q = (int)(en & 4095u);
+        s = (int)((en >> 12) & 0xFFFFFu);
+        const uint32_t toff = (uint32_t)((en >> 32) & 0xFFFFFu);
+        const int seql = (int)(en >> 52);
+        const int mo = P.minoverlap, me = P.maxerrors;
+        const int d = q - p;                             // sequence index = read index + d
+        const int a = d < 0 ? -d : 0;
+        const int L = (rl < seql - d ? rl : seql - d) - a;
+        // most false candidates die here, on the first 16 bases of the diagonal: compared as 2-bit
+        // codes (bytes that are equal have equal codes: this never rejects what the bytes accept)
+        bool alive = L > 0;
+        if (alive && L >= 16) alive = diff_codes(cdp32(roff + (uint32_t)a), tab2_32(tab2, toff + (uint32_t)(a + d))) <= me;
+        // which reference loops visit this diagonal
+        bool canAB = false, canC = false;
+        const bool guard = rl > mo && seql > mo;
+        if (alive) {
+            if (d < 0) {
+                const int i = -d;
+                if (i <= rl - seql) { canC = true; lenC = seql; sposC = -i; keyC = (2u << 30) | (uint32_t)i; }              // 1147
+                else if (guard && i <= rl - mo) { canAB = true; lenAB = rl - i; sposAB = -i; keyAB = (0u << 30) | (uint32_t)(rl - mo - i); }   // 1116
+            } else if (d == 0) {
+                canC = true; lenC = rl > seql ? seql : rl; sposC = 0; keyC = 2u << 30;                                         // 1147 / 1163
+            } else {
+                const int i = d;
+                if (guard && i <= seql - mo && i >= seql - rl) { canAB = true; lenAB = seql - i; sposAB = i; keyAB = (1u << 30) | (uint32_t)(seql - mo - i); }   // 1130
+                if (rl <= seql && i <= seql - rl) { canC = true; lenC = rl; sposC = i; keyC = (2u << 30) | (uint32_t)i; }       // 1163
+            }
+        }
+        if (canAB || canC) {
+            // byte-exact mismatch count of the whole overlap
+            int mism = 0, j = 0;
+            const GlbBytes x = text + roff + (uint32_t)a, y = P.tab + toff + (uint32_t)(a + d);
+            for (; j + 4 <= L && mism <= me; j += 4) mism += diff_bytes(glb_u32(x + j), glb_u32(y + j));
+            for (; j < L && mism <= me; j++) mism += (x[j] != y[j]);
+            if (mism <= me) {
+                // canonical discoverer: no live seed earlier in the order
+                // [ALL-index read blocks by position] then [ANCHOR blocks by number]
+                bool earlier = false;
+                for (int jj = 0; jj <= me && !earlier; jj++) {
+                    const int ph = jj * SK, pt = rl - (jj + 1) * SK;
+                    if (ph + SK <= rl && (kind == 0u || ph < p)) earlier = seed_live_bp(tab2, roff, rl, ph, toff, seql, ph + d);
+                    if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live_bp(tab2, roff, rl, pt, toff, seql, pt + d);
+                }
+                if (kind == 0u) {
+                    for (int jj = 0; jj <= me && !earlier; jj++)
+                        for (int sft = 0; sft < stride && !earlier; sft++) {
+                            const int o = jj * SK + sft;
+                            if (o < q && ((o - d) & (stride - 1)) == 0) earlier = seed_live_bp(tab2, roff, rl, o - d, toff, seql, o);
+                        }
+                }
+                if (!earlier) { hitAB = canAB; hitC = canC; }
+            }
+        }
+    }
+    emit_cold(P.cold, hitAB, fpos, s, sposAB, lenAB, rl, keyAB);
+    emit_cold(P.cold, hitC, fpos, s, sposC, lenC, rl, keyC);
+}
+
+// one 16-byte vector of text -> 16 newline bits, 16 good bits, 32 code bits
+__device__ __forceinline__ void bp_vector(const uint4 v, uint32_t addk, uint32_t &nl16, uint32_t &g16, uint32_t &c32)
+{
+    const uint32_t x[4] = { v.x, v.y, v.z, v.w };
+    uint32_t nf[4], gf[4], cc[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        nf[d] = kvq_nl_flags(x[d]);
+        gf[d] = good_flags(x[d], addk);
+        cc[d] = __builtin_amdgcn_udot4(x[d] & 0x06060606u, 0x40100401u, 0u, false);     // twice the 8-bit code of the four bytes
+    }
+    nl16 = kvq_flags16(nf[0], nf[1], nf[2], nf[3]);
+    g16 = kvq_flags16(gf[0], gf[1], gf[2], gf[3]);
+    c32 = ((cc[0] | (cc[1] << 8)) >> 1) | ((cc[2] | (cc[3] << 8)) << 15);
+}
+
+#ifndef BP_PREFETCH
+#define BP_PREFETCH 0              // the next tile's text: 1 = fetched into registers one tile ahead (20 VGPRs live through the tile),
+#endif                             // 0 = fetched at the start of its tile, 2 = the same, but touched during the tile before (one dword per thread brings the lines into L2)
+#ifndef BP_OCC
+#define BP_OCC 8                   // waves per SIMD the kernel is built for (8: four workgroups per CU, 64 VGPRs)
+#endif
+template <int SS, bool STAMPS>
+__global__ void __launch_bounds__(ST_THREADS, BP_OCC)
+kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__restrict__ data, int64_t fpos_base,
+            const uint4 *__restrict__ tiles, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg,
+            uint32_t tile_bytes, unsigned int *__restrict__ tile_ctr)
+{
+    __shared__ __align__(16) BpLds S;
+    uint8_t *const lds_raw = reinterpret_cast<uint8_t *>(&S);
+    int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = rfl((uint32_t)tid >> 6);
+    if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t *)lds_raw) != 0u) __builtin_trap();   // lds_u32_at
+    const bool younger = wave >= 4u;
+    HotParams P;
+    P.cold = Pg; P.tab = (GlbBytes)Pg->tab; P.maxerrors = Pg->maxerrors; P.minoverlap = Pg->minoverlap;
+    P.minreadlength = Pg->minreadlength; P.amin = Pg->amin;
+    const GlbWords tab2 = (GlbWords)X.tab2;
+    const __attribute__((address_space(1))) uint8_t *const bmL = (const __attribute__((address_space(1))) uint8_t *)X.bm1 + 8192;
+    unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_t = 0, wave_p34 = 0;
+#define BSTAMP(i) do { if constexpr (STAMPS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
+
+    for (int i = tid; i < 2048; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = X.bm1[i];
+    for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) S.hist[i] = 0;
+    if (tid == 0) { S.longest_p1 = 0; S.records = 0; S.fallback = 0; }
+    if (tid < 8) { S.cdp[BP_WIN / 16 + tid] = 0; S.gdp[BP_WIN / 32 + tid] = 0; }    // slack behind the planes
+
+    static_assert(ST_ROUNDS * 16u == ST_BLK, "one scan block per thread");
+    static_assert(ST_WAVES == 8, "eight wave totals");
+    uint4 pre[ST_ROUNDS];
+    const uint32_t blk = (uint32_t)tid * ST_BLK;                           // the block's place in the window
+    const uint32_t toff = blk - ST_PRE;                                    // ... and in the tile's text (tid >= 1)
+    const uint32_t vo = tid ? toff : ST_NO_BLOCK;
+    if (BP_PREFETCH == 1 && blockIdx.x < ntiles) {
+        const TileGeo J = tile_geo(blockIdx.x, tiles, tile_bytes);
+        tile_load80(data, J.load_lo, J.load_hi, vo, pre);
+    }
+    if (tid == 0) S.next_tile = atomicAdd(tile_ctr, 1u);
+    __syncthreads();
+
+    const uint32_t addk = (uint32_t)(0x80 - P.amin) * 0x01010101u;
+    uint32_t tiles_done = 0;
+    uint32_t gn = rfl(S.next_tile);
+    for (uint32_t g = blockIdx.x; g < ntiles; ) {
+        const TileGeo J = tile_geo(g, tiles, tile_bytes);
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        if constexpr (STAMPS) stamp_t = __builtin_amdgcn_s_memtime();
+        if (BP_PREFETCH != 1) tile_load80(data, J.load_lo, J.load_hi, vo, pre);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0)
+
+        // ---- P0: registers -> planes and newline flags of the thread's block; the next tile's loads go out ----
+        const uint32_t own_end_l = J.own_end - J.g0 + ST_PRE;              // ownership ends here
+        const uint32_t end_l = J.load_hi - J.g0 + ST_PRE;                  // end of the loaded text
+        const GlbBytes text = (GlbBytes)data + J.g0 - ST_PRE;              // window offset 0 (never read below ST_PRE)
+        uint32_t nlw[ST_ROUNDS];
+        const uint32_t blk_lo = J.g0 + toff;
+        // only the block with the chunk's first byte (when that is not 16-byte aligned) and the block with
+        // its last byte need masks: their wave zeroes the bytes outside [own_begin, load_hi) in place
+        // (rare: the straight-line code below never sees it)
+        const bool edge = tid && (blk_lo < J.own_begin || (blk_lo < J.load_hi && J.load_hi < blk_lo + ST_BLK && (J.load_hi & 15u)));
+        if (__any(edge)) {
+#pragma unroll
+            for (int r = 0; r < (int)ST_ROUNDS; r++) {
+                const uint32_t gp = blk_lo + 16u * r;
+                uint32_t x[4] = { pre[r].x, pre[r].y, pre[r].z, pre[r].w };
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t keep = (tid && gp < J.load_hi) ? kvq_range_flags(gp + 4u * d, J.own_begin, J.load_hi) : 0u;   // 0x80 per byte inside
+                    x[d] &= (keep >> 7) * 0xFFu;
+                }
+                pre[r] = make_uint4(x[0], x[1], x[2], x[3]);
+            }
+        }
+        KVQ_MARK("P0 vectors");
+        {
+            const uint32_t ga = BP_LDS_GDP + 10u * (uint32_t)tid, ca = 20u * (uint32_t)tid;
+#pragma unroll
+            for (int r = 0; r < (int)ST_ROUNDS; r++) {
+                uint32_t g16, c32;
+                bp_vector(pre[r], addk, nlw[r], g16, c32);
+                *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(ga + 2u * r)) = (uint16_t)g16;
+                *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(ca + 4u * r)) = c32;
+            }
+        }
+        KVQ_MARK("P0 vectors end");
+        // the flags are worked out before the registers are handed to the next tile's loads (left alone
+        // the compiler issues the loads first and keeps a copy of all twenty dwords to do the flags later)
+        __builtin_amdgcn_sched_barrier(0);
+        if (BP_PREFETCH == 1 && gn < ntiles) {
+            const TileGeo N = tile_geo(gn, tiles, tile_bytes);
+            tile_load80(data, N.load_lo, N.load_hi, vo, pre);
+        }
+        static_assert(ST_BLK == 80u, "five vectors per block");
+        uint32_t m0 = nlw[0] | (nlw[1] << 16), m1 = nlw[2] | (nlw[3] << 16), m2 = nlw[4];
+        const uint32_t cnt = (uint32_t)(__popc(m0) + __popc(m1) + __popc(m2));
+        const uint32_t incl = kvq_wave_incl_scan(cnt);
+        if (lane == 63) S.wtot[wave] = incl;
+        KVQ_MARK("P0 scan end");
+        BSTAMP(0);
+        __syncthreads();
+        KVQ_MARK("P1b");
+        BSTAMP(1);
+        uint32_t n_all = 0;
+        {
+            uint32_t run = S.wtot[lane & 7];
+            run += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)run, 0x111, 0xf, 0xf, false);
+            run += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)run, 0x112, 0xf, 0xf, false);
+            run += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)run, 0x114, 0xf, 0xf, false);
+            n_all = (uint32_t)__builtin_amdgcn_readlane((int)run, 7);
+            const uint32_t upto = (uint32_t)__builtin_amdgcn_readlane((int)run, (int)wave);      // ... including this wave
+            uint32_t n = upto - (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) + incl - cnt;
+            if (blk < own_end_l && blk + ST_BLK >= own_end_l) S.n_owned = n + cnt;
+            if (__any(cnt != 0u)) {
+                while (__any((m0 | m1 | m2) != 0u)) {
+                    const bool in0 = m0 != 0u, in1 = m1 != 0u;
+                    const uint32_t w = in0 ? m0 : in1 ? m1 : m2;
+                    if (w) {
+                        const uint32_t pos = blk + (in0 ? 0u : in1 ? 32u : 64u) + (uint32_t)(__ffs((int)w) - 1);
+                        if (n < ST_NLCAP) S.nl[n] = (uint16_t)pos;
+                        n++;
+                        const uint32_t w1 = w & (w - 1u);
+                        if (in0) m0 = w1; else if (in1) m1 = w1; else m2 = w1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        KVQ_MARK("P1b end / P2");
+        BSTAMP(2);
+        uint32_t drawn = 0;
+        if (tid == ST_THREADS - 64) drawn = atomicAdd(tile_ctr, 1u);
+
+        // ---- P2 (every wave, redundantly): which records does this tile own? ----
+        uint32_t nrec = 0, jn = TR_NONE;
+        {
+            const uint32_t n_nl = n_all < ST_NLCAP ? n_all : ST_NLCAP;
+            const uint32_t n_owned = rfl(S.n_owned);
+            uint32_t fallback = n_all > ST_NLCAP ? 1u : 0u;
+            if (J.t == 0) jn = 0;                                            // chunk start: exact
+            else {
+                const uint32_t m = (uint32_t)lane;
+                bool ok = false;
+                if (m >= 1 && m <= 8 && m <= n_owned && m + 2 <= n_nl) {
+                    const uint32_t ls0 = (uint32_t)S.nl[m - 1] + 1u;
+                    const uint32_t ls2 = (uint32_t)S.nl[m + 1] + 1u;
+                    ok = ls0 < end_l && ls2 < end_l && text[ls0] == '@' && text[ls2] == '+';
+                }
+                const uint64_t mk = __ballot(ok);
+                if (mk) jn = (uint32_t)(__ffsll((long long)mk) - 1);
+            }
+            if (jn != TR_NONE) {
+                if (jn <= n_owned) nrec = (n_owned - jn) / 4u + 1u;
+                if (nrec > 0 && jn + 4u * nrec > n_nl) {
+                    const uint32_t fit = n_nl >= jn ? (n_nl - jn) / 4u : 0u;
+                    if (J.load_hi < J.b || n_all > ST_NLCAP) fallback = 1u;
+                    nrec = fit;
+                }
+                if (nrec > ST_RCAP) { nrec = ST_RCAP; fallback = 1u; }
+            }
+            if (tid == 0) {
+                tile_report[g] = (n_owned & 0xFFFFu) | ((jn & 0xFFu) << 16) | (fallback ? TR_FLAG_FALLBACK : 0u);
+                S.records += nrec;
+            }
+        }
+
+        uint32_t touch = 0;
+        if (BP_PREFETCH == 2 && gn < ntiles) {
+            // one dword of every 80 bytes of the next tile: its lines are in L2 when the loads at the end of this tile ask for them
+            const TileGeo N = tile_geo(gn, tiles, tile_bytes);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(data + N.load_lo), 0, (int)(((N.load_hi + 15u) & ~15u) - N.load_lo), 0x00020000);
+            touch = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, 0, 0);
+        }
+        if (dbg & 32u) nrec = 0;                                     // diagnostic: front end only
+        KVQ_MARK("P2 end / P3 setup");
+        BSTAMP(3);
+        if (younger) KVQ_SETPRIO(2); else KVQ_SETPRIO(1);
+        unsigned long long wave_t3 = 0;
+        if constexpr (STAMPS) wave_t3 = __builtin_amdgcn_s_memtime();
+        // ---- P3 / P4 passes: reads -> candidates, then candidates -> hits ----
+        const int64_t tile_fpos = fpos_base + (int64_t)J.g0;
+        static_assert(ST_THREADS == 512, "lg = 9 - ceil(log2(nrec))");
+        const int lg_ = 9 - (nrec > 1u ? 32 - __builtin_clz(nrec - 1u) : 0);
+        const uint32_t lg = lg_ < 0 ? 0u : lg_ > 6 ? 6u : (uint32_t)lg_;
+        const uint32_t G = 1u << lg, RP = ST_THREADS >> lg;
+        const uint32_t gl = (uint32_t)tid & (G - 1u), gr = (uint32_t)tid >> lg;
+        for (uint32_t pass0 = 0; pass0 < nrec; pass0 += RP) {
+            const uint32_t k = pass0 + gr;
+            const bool have = k < nrec;
+            uint32_t roff = 0; int rl = 0;
+            if (have) {
+                const uint32_t m = jn + 4u * k;
+                const uint32_t rstart = m == 0 ? ST_PRE + (J.a - (J.a & ~15u)) : (uint32_t)S.nl[m - 1] + 1u;
+                const uint32_t n0 = S.nl[m], n1 = S.nl[m + 1], n2 = S.nl[m + 2], n3 = S.nl[m + 3];
+                const uint32_t sread = n0 + 1u, plus = n1 + 1u, sscore = n2 + 1u;
+        KVQ_MARK("trim");
+                // the record's '@' and '+' (1037-1048) from global memory, looked at behind the trim
+                uint32_t c0 = '@', cp = '+';
+                if (gl == 0) { c0 = text[rstart]; cp = text[plus]; }
+                // quality trim (1055-1068): this lane's slice of the score line is a bit range of the good plane
+                const int Q = (int)(n3 - sscore);                   // the closing '\n' is implied
+                const int per = (Q + (int)G - 1) >> lg;
+                Seg sg; sg.beg = (int)mul_u24(gl, (uint32_t)per); if (sg.beg > Q) sg.beg = Q;
+                int s1 = sg.beg + per; if (s1 > Q) s1 = Q;
+                sg.len = 0; sg.pre = 0; sg.suf = 0; sg.best = 0; sg.bstart = sg.beg;
+                {
+                    // one round of at most 64 score bits
+                    auto round = [&](int c0_) -> Seg {
+                        const int n = s1 - c0_ < 64 ? s1 - c0_ : 64;
+                        const uint32_t bit = sscore + (uint32_t)c0_;
+                        const uint32_t a = BP_LDS_GDP + ((bit >> 5) << 2), sh = bit & 31u;
+                        const uint32_t d0 = lds_u32_at(a), d1 = lds_u32_at(a + 4u), d2 = lds_u32_at(a + 8u);
+                        const uint64_t nmask = n < 64 ? (1ull << n) - 1ull : ~0ull;
+                        const uint64_t m = (((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh)) & nmask;
+                        Seg sub; sub.beg = c0_; sub.len = n;
+                        int bl, bs;
+                        uint64_t zz = ~m & nmask;                          // the bad bytes of the slice
+                        if (!__any(__popcll(zz) > 4) && !(dbg & 4u)) {
+                            // the usual case, few bad bytes in any lane's slice: walk them (runs = the gaps between them)
+                            int prev = 0, first = n, p; bl = 0; bs = 0;
+                            do {
+                                const uint32_t plo = (uint32_t)(__ffs((int)(uint32_t)zz) - 1), ph = (uint32_t)(__ffs((int)(uint32_t)(zz >> 32)) - 1);
+                                const uint32_t phi = ph > 0xFFFFFFDFu ? 0xFFFFFFFFu : ph + 32u;
+                                uint32_t pm = plo < phi ? plo : phi; if (pm > (uint32_t)n) pm = (uint32_t)n;
+                                p = (int)pm;
+                                zz &= zz - 1ull;
+                                first = first < p ? first : p;
+                                const int gap = p - prev;
+                                if (gap > bl) { bl = gap; bs = prev; }
+                                prev = p < n ? p + 1 : prev;
+                            } while (__any(p < n));
+                            sub.pre = first; sub.suf = n - prev;
+                        } else {
+                            const uint64_t inv = ~m;
+                            sub.pre = inv ? __ffsll((long long)inv) - 1 : 64; if (sub.pre > n) sub.pre = n;
+                            const uint64_t top = ~(m << (64 - n));         // leading ones of the n-bit mask = trailing run
+                            sub.suf = top ? __clzll((long long)top) : 64; if (sub.suf > n) sub.suf = n;
+                            longest_run64(m, n, bl, bs);
+                        }
+                        sub.best = bl; sub.bstart = c0_ + bs;
+                        return sub;
+                    };
+                    if (!__any(per > 64)) sg = round(sg.beg);
+                    else {
+                        for (int cc = sg.beg; cc < s1; cc += 64) {
+                            const Seg sub = round(cc);
+                            sg = (cc == sg.beg) ? sub : seg_merge(sg, sub);
+                        }
+                    }
+                }
+                // ordered tree merge over the G lanes of the read
+                if (G == 4u) {
+#define KVQ_QUAD(v, ctl) __builtin_amdgcn_update_dpp(0, (v), (ctl), 0xf, 0xf, true)
+                    {
+                        Seg B;                                                       // lane ^ 1: quad_perm [1,0,3,2]
+                        B.len = KVQ_QUAD(sg.len, 0xB1); B.pre = KVQ_QUAD(sg.pre, 0xB1); B.suf = KVQ_QUAD(sg.suf, 0xB1);
+                        B.best = KVQ_QUAD(sg.best, 0xB1); B.bstart = KVQ_QUAD(sg.bstart, 0xB1); B.beg = 0;
+                        sg = seg_merge(sg, B);
+                    }
+                    {
+                        Seg B;                                                       // lane ^ 2: quad_perm [2,3,0,1]
+                        B.len = KVQ_QUAD(sg.len, 0x4E); B.pre = KVQ_QUAD(sg.pre, 0x4E); B.suf = KVQ_QUAD(sg.suf, 0x4E);
+                        B.best = KVQ_QUAD(sg.best, 0x4E); B.bstart = KVQ_QUAD(sg.bstart, 0x4E); B.beg = 0;
+                        sg = seg_merge(sg, B);
+                    }
+                    rl = KVQ_QUAD(sg.best, 0x00);
+                    roff = sread + (uint32_t)KVQ_QUAD(sg.bstart, 0x00);              // 1070
+#undef KVQ_QUAD
+                } else {
+                    for (uint32_t d = 1; d < G; d <<= 1) {
+                        Seg B;
+                        B.len = __shfl_xor(sg.len, (int)d, 64); B.pre = __shfl_xor(sg.pre, (int)d, 64); B.suf = __shfl_xor(sg.suf, (int)d, 64);
+                        B.best = __shfl_xor(sg.best, (int)d, 64); B.bstart = __shfl_xor(sg.bstart, (int)d, 64); B.beg = 0;
+                        if ((gl & d) == 0) sg = seg_merge(sg, B);
+                    }
+                    rl = __shfl(sg.best, lane & ~(int)(G - 1u), 64);
+                    roff = sread + (uint32_t)__shfl(sg.bstart, lane & ~(int)(G - 1u), 64);             // 1070
+                }
+                if (gl == 0) {
+                    if (c0 != '@') atomicMin(Pg->err, ((unsigned long long)(tile_fpos + rstart - ST_PRE) << 16) | (0ull << 8) | c0);
+                    else if (cp != '+') atomicMin(Pg->err, ((unsigned long long)(tile_fpos + plus - ST_PRE) << 16) | (1ull << 8) | cp);
+                    if (rl < KVQ_RL_BINS) atomicAdd(&S.hist[rl >> 1], 1u << (16 * (rl & 1)));          // 394-402
+                    atomicMax(&S.longest_p1, (uint32_t)(rl + 1));
+                    S.rinfo[k] = roff | ((uint32_t)rl << 16);
+                }
+            }
+        KVQ_MARK("trim end / filter");
+            BSTAMP(4);
+            KVQ_SETPRIO(2);
+            // filter + verify, wave by wave (the wave's reads, candidates and work items are its own)
+            const uint32_t rpw = 64u >> lg, grw = (uint32_t)lane >> lg;
+            const uint32_t wfirst = pass0 + wave * rpw;
+            const uint32_t npass = wfirst < nrec ? (nrec - wfirst < rpw ? nrec - wfirst : rpw) : 0u;
+            uint32_t *const q1 = S.q1 + wave * BP_QW; uint32_t *const q2 = S.q2 + wave * BP_Q2W;
+            uint32_t sub = 0, step = rpw;
+            while (sub < npass) {
+                const bool mine = have && rl >= P.minreadlength && !(dbg & 2u) && grw >= sub && grw - sub < step;       // 1100
+                uint32_t qn = 0;
+                int e0 = 0, e1 = 0;
+                if (mine) {
+                    const int NPe = (rl - SK) / SS + 1;
+                    const int per = (NPe + (int)G - 1) >> lg;
+                    e0 = (int)mul_u24(gl, (uint32_t)per); if (e0 > NPe) e0 = NPe;
+                    e1 = e0 + per; if (e1 > NPe) e1 = NPe;
+                }
+                const int me_ = P.maxerrors;
+                // is the 8-mer at read position pp anywhere in a sequence?  (bitmap of all sequence 8-mers: global memory)
+                auto fixed_block = [&](int pp, bool ok) -> bool {
+                    const uint32_t code = cdp_code8(roff + (uint32_t)(ok ? pp : 0));
+                    return ok && ((bmL[code >> 3] >> (code & 7u)) & 1u);
+                };
+                auto head_ok = [&](int jj) { return mine && jj <= me_ && (jj + 1) * SK <= rl; };
+                auto tail_ok = [&](int jj) { const int pp = rl - (jj + 1) * SK; return mine && jj <= me_ && pp >= 0 && !((pp % SK) == 0 && pp <= me_ * SK); };
+                const bool hhit = fixed_block((int)gl * SK, head_ok((int)gl));
+                const bool thit = fixed_block(rl - ((int)gl + 1) * SK, tail_ok((int)gl));
+                constexpr int NR = SS == 8 ? 6 : 48 / SS;                        // lookups per lane and round
+                bool first = true;
+                for (int ee = e0; __any(ee < e1); ee += NR, first = false) {
+                    const bool act = ee < e1;
+                    uint32_t hA = 0;                                             // bit j: lookup ee + j met an anchor code
+                    {
+                        // the read's bases are a bit range of the code plane: position roff + SS * ee on
+                        const uint32_t pos = roff + (uint32_t)SS * (uint32_t)(act ? ee : 0);
+                        const uint32_t a = (pos >> 2) & ~3u, bo = (pos & 15u) * 2u;
+                        constexpr int NW = (2 * SS * (NR - 1) + 16 + 31) / 32 + 1;   // words that hold NR codes at any alignment
+                        uint32_t W[NW];
+#pragma unroll
+                        for (int t = 0; t < NW; t++) W[t] = lds_u32_at(a + 4u * (uint32_t)t);
+                        uint32_t R[NW - 1];
+#pragma unroll
+                        for (int t = 0; t < NW - 1; t++) R[t] = __builtin_amdgcn_alignbit(W[t + 1], W[t], bo);
+                        constexpr int NB = SS == 8 ? 6 : 8;
+#pragma unroll
+                        for (int j0 = 0; j0 < NR; j0 += NB) {
+                            uint32_t bi[NB], bb[NB];
+#pragma unroll
+                            for (int u = 0; u < NB; u++) {
+                                const int b = 2 * SS * (j0 + u), wj = b >> 5, o = b & 31;
+                                // the code is bits o .. o + 15 of R[wj] (and of R[wj + 1] when it crosses the word)
+                                const uint32_t word = o <= 16 ? R[wj] : __builtin_amdgcn_alignbit(R[wj + 1 < NW - 1 ? wj + 1 : wj], R[wj], 16);
+                                const uint32_t off = (uint32_t)(o <= 16 ? o : o - 16);
+                                bi[u] = __builtin_amdgcn_ubfe(word, off, 3u);
+                                bb[u] = lds_byte_at(BP_LDS_BMA + __builtin_amdgcn_ubfe(word, off + 3u, 13u));
+                            }
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int u = 0; u < NB; u++) hA |= __builtin_amdgcn_ubfe(bb[u], bi[u], 1u) << (j0 + u);
+                        }
+                    }
+                    const int nv = act ? (e1 - ee < NR ? e1 - ee : NR) : 0;
+                    hA &= (1u << nv) - 1u;                                      // nv <= 24
+                    const bool hh = first && hhit, th = first && thit;
+                    const uint32_t c = (uint32_t)__popc(hA) + (hh ? 1u : 0u) + (th ? 1u : 0u);
+                    const uint32_t inc = kvq_wave_incl_scan(c);
+                    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                    if (tot) {
+                        uint32_t idx = qn + inc - c;
+                        while (hA) {
+                            const int j = __ffs((int)hA) - 1; hA &= hA - 1u;
+                            if (idx < BP_QW) q1[idx] = k | ((uint32_t)(SS * (ee + j)) << 9);        // beyond the cap: dropped, the stretch is redone in halves
+                            idx++;
+                        }
+                        if (hh) { if (idx < BP_QW) q1[idx] = k | ((gl * SK) << 9) | (1u << 21); idx++; }
+                        if (th && idx < BP_QW) { const uint32_t pt = (uint32_t)(rl - ((int)gl + 1) * SK); q1[idx] = k | (pt << 9) | (1u << 21); }
+                        qn += tot;
+                    }
+                }
+                // groups narrower than e+1 lanes: the remaining head and tail blocks, one push round each
+                for (int t = (int)G; t <= me_; t += (int)G) {
+                    const int jj = t + (int)gl;
+#pragma unroll
+                    for (int side = 0; side < 2; side++) {
+                        const int pp = side ? rl - (jj + 1) * SK : jj * SK;
+                        const bool hit = fixed_block(pp, side ? tail_ok(jj) : head_ok(jj));
+                        const uint64_t mm = __ballot(hit);
+                        if (mm) {
+                            const uint32_t idx = qn + (uint32_t)__popcll(mm & kvq_lanemask_lt());
+                            if (hit && idx < BP_QW) q1[idx] = k | ((uint32_t)pp << 9) | (1u << 21);
+                            qn += (uint32_t)__popcll(mm);
+                        }
+                    }
+                }
+        KVQ_MARK("filter end / P4a");
+                BSTAMP(5);
+                KVQ_SETPRIO(3);
+
+                // ---- P4a: one candidate per lane: index range -> (candidate, entry) work items ----
+                const bool over1 = qn > BP_QW;                            // candidates were dropped
+                const uint32_t qn_ok = (over1 || (dbg & 1u)) ? 0u : qn;
+                uint32_t q2n = 0;
+                for (uint32_t q0 = 0; q0 < qn_ok; q0 += 64u) {
+                    const uint32_t qi = q0 + lane;
+                    uint32_t en0 = 0, ne = 0;
+                    if (qi < qn_ok) {
+                        const uint32_t cd = q1[qi];
+                        const uint32_t code = cdp_code8((S.rinfo[cd & 511u] & 0xFFFFu) + ((cd >> 9) & 4095u));
+                        const uint32_t *st = (cd >> 21) ? X.start_all : X.start_anc;
+                        en0 = st[code]; ne = st[code + 1u] - en0;
+                    }
+                    const uint32_t inc = kvq_wave_incl_scan(ne);
+                    const uint32_t base = q2n + inc - ne;
+                    for (uint32_t j = 0; j < ne; j++)
+                        if (base + j < BP_Q2W) q2[base + j] = (qi << 22) | (en0 + j);
+                    q2n += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                }
+                const bool over = over1 || q2n > BP_Q2W;
+                if (over && step > 1u) { step >>= 1; continue; }
+                if (over && lane == 0) S.fallback = 1u;                   // one read floods the queues: the batch goes to the exhaustive kernels
+
+        KVQ_MARK("P4b");
+                // ---- P4b: one work item per lane ----
+                {
+                    const uint32_t q2n_ok = over ? 0u : q2n;
+                    for (uint32_t i0 = 0; i0 < q2n_ok; i0 += 64u) {
+                        const uint32_t ii = i0 + lane;
+                        const bool active = ii < q2n_ok;
+                        uint32_t rec = 0, kind = 0; int p = 0; uint64_t en = 0;
+                        if (active) {
+                            const uint32_t it = q2[ii];
+                            const uint32_t cd = q1[it >> 22];
+                            rec = cd & 511u; p = (int)((cd >> 9) & 4095u); kind = cd >> 21;
+                            en = (kind ? X.ent_all : X.ent_anc)[it & 0x3FFFFFu];
+                        }
+                        verify_item_bp(P, S, tab2, text, active, rec, p, kind, en, tile_fpos, SS);
+                    }
+                }
+                KVQ_SETPRIO(2);
+                sub += step;
+            }
+            KVQ_SETPRIO(0);
+        KVQ_MARK("P4 end");
+            BSTAMP(6);
+        }
+        if constexpr (STAMPS) wave_p34 += __builtin_amdgcn_s_memtime() - wave_t3;
+        if (BP_PREFETCH == 2) asm volatile("" :: "v"(touch));       // (the touch has come back long ago; this only keeps it alive)
+        // everyone is done with the tile's planes before the next tile's fill
+        if (tid == ST_THREADS - 64) S.next_tile = drawn;
+        __syncthreads();
+        KVQ_MARK("tile end");
+        BSTAMP(7);
+        if (tid == 0 && S.fallback) { atomicOr(&tile_report[g], TR_FLAG_FALLBACK); S.fallback = 0; }
+        g = gn; gn = rfl(S.next_tile);
+        if (++tiles_done == ST_HIST_TILES) {
+            for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) {
+                const uint32_t w = S.hist[i];
+                if (w & 0xFFFFu) atomicAdd(&Pg->ctr[KVQ_CTR_RL_ + 2 * i], (unsigned long long)(w & 0xFFFFu));
+                if (w >> 16) atomicAdd(&Pg->ctr[KVQ_CTR_RL_ + 2 * i + 1], (unsigned long long)(w >> 16));
+                S.hist[i] = 0;
+            }
+            tiles_done = 0;
+            __syncthreads();
+        }
+    }
+
+    unsigned long long *const ctr = Pg->ctr;
+    if constexpr (STAMPS) {
+        if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
+        if (lane == 0) atomicAdd(&ctr[KVQ_CTR_RL_ + 908 + wave], wave_p34);
+    }
+    for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) {
+        const uint32_t w = S.hist[i];
+        if (w & 0xFFFFu) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i], (unsigned long long)(w & 0xFFFFu));
+        if (w >> 16) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i + 1], (unsigned long long)(w >> 16));
+    }
+    if (tid == 0) {
+        if (S.longest_p1) atomicMax(&ctr[KVQ_CTR_LONGEST_], (unsigned long long)S.longest_p1);
+        if (S.records) atomicAdd(&ctr[KVQ_CTR_RECORDS_], (unsigned long long)S.records);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launch (both scan kernels)
+// ---------------------------------------------------------------------------
+
+int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
+                      const uint32_t *d_chunk_off, int64_t nchunks, int64_t fpos_base, uint32_t max_chunk_bytes)
+{
+    (void)nbytes; (void)max_chunk_bytes;
+    SeedIndex *ix = s->t->index;
+    // tiles per chunk; the tables live in the scan's pool so that nothing here waits for the GPU
+    const std::vector<int64_t> &co = s->cur_chunk_off;
+    if (s->tile_bytes == 0) {
+        // first batch of a device-resident scan: look at the head of the text once (the choice is kept
+        // across kvq_scan_reset; host batches are sized on the host, kvq_scan_host_async)
+        const size_t n = (size_t)std::min<int64_t>(nbytes, 128 << 10);
+        std::vector<uint8_t> head(n);
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        KVQ_HIP(hipMemcpy(head.data(), d_data, n, hipMemcpyDeviceToHost));
+        s->tile_bytes = kvq_tile_for_text(head.data(), n);
+    }
+    const uint32_t TILE = s->tile_bytes;
+    uint64_t nt = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
+        nt += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
+    }
+    if (nt == 0) return KVQ_OK;
+    // workgroups per launch: what the CUs hold at once (kvq_scan_bp four per CU, kvq_scan_seeded two)
+    static const uint32_t grid_env = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 0);
+    const uint32_t grid_cap = grid_env ? grid_env : ix->variant ? 512u : 1024u;
+    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 8192 > s->pool.cap) {       // run_batch made the room
+        kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;
+    }
+    // first tile of every chunk, then the parameter block: one copy
+    const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
+    const size_t first_at = s->pool.take(first_b + sizeof(KvqParams) + 16);      // ... and the tile counter behind it
+    const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 4);
+    uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
+    uint64_t acc = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
+        first[c] = (uint32_t)acc;
+        acc += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
+    }
+    first[nchunks] = (uint32_t)acc;
+    memcpy(s->pool.h + first_at + first_b, &P, sizeof(KvqParams));
+    const uint32_t grid_seeded = (uint32_t)std::min<uint64_t>(nt, grid_cap);
+    memcpy(s->pool.h + first_at + first_b + sizeof(KvqParams), &grid_seeded, 4);           // tiles below this number are the workgroups' first
+    uint32_t *d_first = reinterpret_cast<uint32_t *>(s->pool.d + first_at);
+    const KvqParams *d_params = reinterpret_cast<const KvqParams *>(s->pool.d + first_at + first_b);
+    uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
+    uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
+    // chunk offsets (run_batch put them right in front), first tiles, parameters, tile counter: one transfer
+    KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, first_at + first_b + sizeof(KvqParams) + 16 - s->cur_co_at,
+                           hipMemcpyHostToDevice, s->stream));
+    unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + first_at + first_b + sizeof(KvqParams));
+    hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
+
+    typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t, unsigned int *);
+    static const SeededKernel kernels[12] = { kvq_scan_bp<2, false>, kvq_scan_bp<4, false>, kvq_scan_bp<8, false>,
+                                              kvq_scan_bp<2, true>, kvq_scan_bp<4, true>, kvq_scan_bp<8, true>,
+                                              kvq_scan_seeded<2, false>, kvq_scan_seeded<4, false>, kvq_scan_seeded<8, false>,
+                                              kvq_scan_seeded<2, true>, kvq_scan_seeded<4, true>, kvq_scan_seeded<8, true> };
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (int i = 6; i < 12; i++)
+            KVQ_HIP(hipFuncSetAttribute((const void *)kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
+        attr_set = true;
+    }
+    static const uint32_t dbg = (uint32_t)(getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0);
+    {
+        const uint32_t grid = grid_seeded;
+        const SeededKernel kern = kernels[(ix->variant ? 6 : 0) + (ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0) + ((dbg & 16u) ? 3 : 0)];
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), 0, s->stream, d_params, ix->dev, d_data, fpos_base,
+                           reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg, TILE, d_tile_ctr);
+    }
+    hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
+                       d_first, d_report, s->cur_fail);
+    KVQ_HIP(hipGetLastError());
+    if (getenv("KVQ_DBG_REPORT")) {
+        // diagnostic: replay kvq_validate_tiles on the host and name the tiles it rejects
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        std::vector<uint32_t> rep((size_t)nt);
+        KVQ_HIP(hipMemcpy(rep.data(), d_report, (size_t)nt * 4, hipMemcpyDeviceToHost));
+        for (int64_t c = 0; c < nchunks; c++) {
+            uint32_t seen = 0, total = 0;
+            for (uint32_t g = first[c]; g < first[c + 1]; g++) total += rep[g] & 0xFFFFu;
+            for (uint32_t g = first[c]; g < first[c + 1]; g++) {
+                if (kvq_tile_report_bad(rep[g], g == first[c], seen, total))
+                    fprintf(stderr, "tile %u (chunk %lld [%lld, %lld), tile %u of it): report %08x n_owned %u jn %u seen %u of %u\n",
+                            g, (long long)c, (long long)co[c], (long long)co[c + 1], g - first[c], rep[g], rep[g] & 0xFFFFu, (rep[g] >> 16) & 0xFFu, seen, total);
+                seen += rep[g] & 0xFFFFu;
+            }
+        }
+    }
+    return KVQ_OK;
+}

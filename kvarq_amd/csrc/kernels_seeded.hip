@@ -63,25 +63,18 @@
 #define TR_FLAG_FALLBACK 0x2000000u
 
 struct SeedTables {
-    const uint32_t *bm2;                      // 2 bits per 8-mer code: bit 0 = an anchor block, bit 1 = anywhere in a sequence (planes kernel)
-    const uint32_t *bm1;                      // the same as two bitmaps of 8 KiB, one bit per code: anchor blocks, then anywhere
+    const uint32_t *bm1;                      // two bitmaps of 8 KiB, one bit per 8-mer code: anchor blocks, then anywhere in a sequence
     const uint32_t *start_anc, *start_all;    // CSR starts, 65537 entries
     // entry: position in sequence (12) | sequence number (20) | table offset of the sequence (20) | its length (12)
     const uint64_t *ent_anc, *ent_all;
+    const uint32_t *tab2;                     // the sequence table as 2-bit codes, 16 bases per word (kernels_bp.hip)
     int32_t stride;                           // read positions 0, stride, 2*stride, ... are looked up for anchors (2, 4 or 8)
 };
 
-// the planes kernel (kernels_planes.hip)
-extern "C" __global__ void kvq_scan_planes(KvqParams P, SeedTables X, const uint8_t *__restrict__ data, int64_t fpos_base,
-                                           const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ tile_chunk,
-                                           const uint32_t *__restrict__ tile_first, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg);
-size_t kvq_planes_lds_bytes();
-uint32_t kvq_planes_tile_bytes();
-
 struct SeedIndex {
-    int variant = 0;          // 0 = kvq_scan_seeded, 1 = kvq_scan_planes (KVQ_KERNEL=planes)
+    int variant = 0;          // 0 = kvq_scan_bp (kernels_bp.hip), 1 = kvq_scan_seeded (KVQ_KERNEL=v1)
     int stride = 2;           // anchor blocks sit at sequence offsets 8j + 0 .. 8j + stride - 1
-    DevBuf d_bm2, d_bm1, d_start_anc, d_start_all, d_ent_anc, d_ent_all;
+    DevBuf d_bm1, d_start_anc, d_start_all, d_ent_anc, d_ent_all, d_tab2;
     SeedTables dev;
 };
 
@@ -103,7 +96,7 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     if (e < 0 || e > 6) return nullptr;
     const int need = (e + 1) * SK;
     const char *kv = getenv("KVQ_KERNEL");
-    const int variant = (kv && !strcmp(kv, "planes")) ? 1 : 0;      // which kernel walks the text; the index is the same
+    const int variant = (kv && !strcmp(kv, "v1")) ? 1 : 0;          // which kernel walks the text; the index is the same
     // every accepted alignment must be at least `need` long: class A/B overlaps
     // are >= minoverlap, class C lengths are min(readlength, sequence length)
     if (cfg.minoverlap < need || cfg.minreadlength < need) return nullptr;
@@ -127,7 +120,6 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     // must be able to hold its shifted blocks: length >= 8(e+1) + stride - 1.
     int stride = minlen >= need + 7 ? 8 : minlen >= need + 3 ? 4 : 2;
     if (const char *sv = getenv("KVQ_STRIDE")) { const int w = atoi(sv); if ((w == 2 || w == 4 || w == 8) && w <= stride) stride = w; }
-    if (variant == 1) stride = 2;                               // the planes kernel looks up every even position
 
     std::vector<std::pair<uint32_t, uint64_t>> anc, all;       // (code, entry)
     for (int s : t->seeded) {
@@ -140,13 +132,11 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     }
     SeedIndex *ix = new SeedIndex();
     ix->variant = variant; ix->stride = stride;
-    std::vector<uint32_t> bm2(4096, 0);
     std::vector<uint8_t> bm1(16384, 0);
     auto upload = [&](std::vector<std::pair<uint32_t, uint64_t>> &v, int bit, DevBuf &st, DevBuf &en) -> bool {
         std::sort(v.begin(), v.end());
         std::vector<uint32_t> start(65537, 0); std::vector<uint64_t> ent(v.size() + 1, 0);
         for (size_t i = 0; i < v.size(); i++) {
-            bm2[v[i].first >> 4] |= 1u << (2 * (v[i].first & 15) + bit);
             bm1[(size_t)bit * 8192 + (v[i].first >> 3)] |= (uint8_t)(1u << (v[i].first & 7));
             start[v[i].first + 1]++; ent[i] = v[i].second;
         }
@@ -156,13 +146,24 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
                hipMemcpy(en.p, ent.data(), ent.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
     };
     if (!upload(anc, 0, ix->d_start_anc, ix->d_ent_anc) || !upload(all, 1, ix->d_start_all, ix->d_ent_all) ||
-        ix->d_bm2.ensure(16384) != KVQ_OK || hipMemcpy(ix->d_bm2.p, bm2.data(), 16384, hipMemcpyHostToDevice) != hipSuccess ||
         ix->d_bm1.ensure(16384) != KVQ_OK || hipMemcpy(ix->d_bm1.p, bm1.data(), 16384, hipMemcpyHostToDevice) != hipSuccess) {
         if (!kvq_error_code()) kvq_set_error(KVQ_ERR_DEVICE, "uploading the seed index failed");
         kvq_seed_index_destroy(ix);
         return nullptr;
     }
-    ix->dev.bm2 = ix->d_bm2.as<uint32_t>(); ix->dev.bm1 = ix->d_bm1.as<uint32_t>();
+    ix->dev.bm1 = ix->d_bm1.as<uint32_t>();
+    {
+        // the table as 2-bit codes (byte >> 1) & 3, base i in bits 2(i & 15) of word i >> 4 (two words of slack)
+        const size_t nb = t->h_tab.size();
+        std::vector<uint32_t> t2(nb / 16 + 3, 0);
+        for (size_t i = 0; i < nb; i++) t2[i >> 4] |= code2_of(t->h_tab[i]) << (2 * (i & 15));
+        if (ix->d_tab2.ensure(t2.size() * 4) != KVQ_OK || hipMemcpy(ix->d_tab2.p, t2.data(), t2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            if (!kvq_error_code()) kvq_set_error(KVQ_ERR_DEVICE, "uploading the seed index failed");
+            kvq_seed_index_destroy(ix);
+            return nullptr;
+        }
+        ix->dev.tab2 = ix->d_tab2.as<uint32_t>();
+    }
     ix->dev.start_anc = ix->d_start_anc.as<uint32_t>(); ix->dev.start_all = ix->d_start_all.as<uint32_t>();
     ix->dev.ent_anc = ix->d_ent_anc.as<uint64_t>(); ix->dev.ent_all = ix->d_ent_all.as<uint64_t>();
     ix->dev.stride = stride;
@@ -172,7 +173,7 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
 void kvq_seed_index_destroy(SeedIndex *ix)
 {
     if (!ix) return;
-    DevBuf *b[] = { &ix->d_bm2, &ix->d_bm1, &ix->d_start_anc, &ix->d_start_all, &ix->d_ent_anc, &ix->d_ent_all };
+    DevBuf *b[] = { &ix->d_tab2, &ix->d_bm1, &ix->d_start_anc, &ix->d_start_all, &ix->d_ent_anc, &ix->d_ent_all };
     for (DevBuf *x : b) x->release();
     delete ix;
 }
@@ -472,7 +473,7 @@ __device__ __forceinline__ void tile_load80(const uint8_t *data, uint32_t lo, ui
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(data + lo), 0, (int)(((hi + 15u) & ~15u) - lo), 0x00020000);
 #pragma unroll
     for (int r = 0; r < (int)ST_ROUNDS; r++) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo + 16u * (uint32_t)r), 0, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, 16 * r, 0);       // (the 16 r as scalar offset: an inline constant)
         pre[r] = make_uint4(v.x, v.y, v.z, v.w);
     }
 }
@@ -1170,97 +1171,3 @@ uint32_t kvq_tile_for_text(const uint8_t *text, size_t n)
     return kvq_choose_tile(maxline, rec_bytes);
 }
 
-int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
-                      const uint32_t *d_chunk_off, int64_t nchunks, int64_t fpos_base, uint32_t max_chunk_bytes)
-{
-    (void)nbytes; (void)max_chunk_bytes;
-    SeedIndex *ix = s->t->index;
-    // tiles per chunk; the tables live in the scan's pool so that nothing here waits for the GPU
-    const std::vector<int64_t> &co = s->cur_chunk_off;
-    if (!ix->variant && s->tile_bytes == 0) {
-        // first batch of a device-resident scan: look at the head of the text once (the choice is kept
-        // across kvq_scan_reset; host batches are sized on the host, kvq_scan_host_async)
-        const size_t n = (size_t)std::min<int64_t>(nbytes, 128 << 10);
-        std::vector<uint8_t> head(n);
-        KVQ_HIP(hipStreamSynchronize(s->stream));
-        KVQ_HIP(hipMemcpy(head.data(), d_data, n, hipMemcpyDeviceToHost));
-        s->tile_bytes = kvq_tile_for_text(head.data(), n);
-    }
-    const uint32_t TILE = ix->variant ? kvq_planes_tile_bytes() : s->tile_bytes;
-    uint64_t nt = 0;
-    for (int64_t c = 0; c < nchunks; c++) {
-        const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
-        nt += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
-    }
-    if (nt == 0) return KVQ_OK;
-    static const uint32_t grid_cap = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 512);   // two workgroups per CU
-    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 8192 > s->pool.cap) {       // run_batch made the room
-        kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;
-    }
-    // first tile of every chunk, then the parameter block: one copy
-    const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
-    const size_t first_at = s->pool.take(first_b + sizeof(KvqParams) + 16);      // ... and the tile counter behind it
-    const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 4);
-    uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
-    uint64_t acc = 0;
-    for (int64_t c = 0; c < nchunks; c++) {
-        const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
-        first[c] = (uint32_t)acc;
-        acc += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
-    }
-    first[nchunks] = (uint32_t)acc;
-    memcpy(s->pool.h + first_at + first_b, &P, sizeof(KvqParams));
-    const uint32_t grid_seeded = (uint32_t)std::min<uint64_t>(nt, grid_cap);
-    memcpy(s->pool.h + first_at + first_b + sizeof(KvqParams), &grid_seeded, 4);           // tiles below this number are the workgroups' first
-    uint32_t *d_first = reinterpret_cast<uint32_t *>(s->pool.d + first_at);
-    const KvqParams *d_params = reinterpret_cast<const KvqParams *>(s->pool.d + first_at + first_b);
-    uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
-    uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
-    // chunk offsets (run_batch put them right in front), first tiles, parameters, tile counter: one transfer
-    KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, first_at + first_b + sizeof(KvqParams) + 16 - s->cur_co_at,
-                           hipMemcpyHostToDevice, s->stream));
-    unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + first_at + first_b + sizeof(KvqParams));
-    hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
-
-    typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t, unsigned int *);
-    static const SeededKernel kernels[6] = { kvq_scan_seeded<2, false>, kvq_scan_seeded<4, false>, kvq_scan_seeded<8, false>,
-                                             kvq_scan_seeded<2, true>, kvq_scan_seeded<4, true>, kvq_scan_seeded<8, true> };
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (SeededKernel kf : kernels)
-            KVQ_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
-        KVQ_HIP(hipFuncSetAttribute((const void *)kvq_scan_planes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kvq_planes_lds_bytes()));
-        attr_set = true;
-    }
-    static const uint32_t dbg = (uint32_t)(getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0);
-    if (ix->variant) {
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, 768);               // up to three workgroups per CU
-        hipLaunchKernelGGL(kvq_scan_planes, dim3(grid), dim3(512), kvq_planes_lds_bytes(), s->stream, P, ix->dev, d_data, fpos_base,
-                           d_chunk_off, d_tchunk, d_first, (uint32_t)nt, d_report, dbg);
-    } else {
-        const uint32_t grid = grid_seeded;
-        const SeededKernel kern = kernels[(ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0) + ((dbg & 16u) ? 3 : 0)];
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), 0, s->stream, d_params, ix->dev, d_data, fpos_base,
-                           reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg, TILE, d_tile_ctr);
-    }
-    hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
-                       d_first, d_report, s->cur_fail);
-    KVQ_HIP(hipGetLastError());
-    if (getenv("KVQ_DBG_REPORT") && !ix->variant) {
-        // diagnostic: replay kvq_validate_tiles on the host and name the tiles it rejects
-        KVQ_HIP(hipStreamSynchronize(s->stream));
-        std::vector<uint32_t> rep((size_t)nt);
-        KVQ_HIP(hipMemcpy(rep.data(), d_report, (size_t)nt * 4, hipMemcpyDeviceToHost));
-        for (int64_t c = 0; c < nchunks; c++) {
-            uint32_t seen = 0, total = 0;
-            for (uint32_t g = first[c]; g < first[c + 1]; g++) total += rep[g] & 0xFFFFu;
-            for (uint32_t g = first[c]; g < first[c + 1]; g++) {
-                if (kvq_tile_report_bad(rep[g], g == first[c], seen, total))
-                    fprintf(stderr, "tile %u (chunk %lld [%lld, %lld), tile %u of it): report %08x n_owned %u jn %u seen %u of %u\n",
-                            g, (long long)c, (long long)co[c], (long long)co[c + 1], g - first[c], rep[g], rep[g] & 0xFFFFu, (rep[g] >> 16) & 0xFFu, seen, total);
-                seen += rep[g] & 0xFFFFu;
-            }
-        }
-    }
-    return KVQ_OK;
-}

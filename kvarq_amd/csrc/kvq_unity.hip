@@ -2,7 +2,7 @@
 // must share one HIP module)
 #include "kernels_general.hip"
 #include "kernels_seeded.hip"
-#include "kernels_planes.hip"
+#include "kernels_bp.hip"
 #include "kernels_results.hip"
 #include "synth.hip"
 #include "kvq_runtime.hip"
