@@ -27,18 +27,28 @@
 #define BP_WIN (ST_BUF + ST_BLK)   // bytes of text a tile's planes cover: 512 blocks of 80
 #define BP_QW 96                   // candidates per wave and stretch
 #define BP_Q2W 96                  // work items per wave and stretch
+#define BP_NLCAP 1920              // newlines per window (beyond: the tile raises its fallback flag)
+#define BP_HEAD 2048u              // bytes of raw text kept for P2
 #define BP_QCAP (BP_QW * ST_WAVES)
 #define BP_Q2CAP (BP_Q2W * ST_WAVES)
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 struct BpLds {
     uint32_t cdp[BP_WIN / 16 + 8];       // code plane: 2 bits per byte, byte o of the window in bits 2o, 2o+1
     uint32_t gdp[BP_WIN / 32 + 8];       // good plane: 1 bit per byte (score byte >= Amin)
-    uint16_t nl[ST_NLCAP];               // window offsets of every '\n', ascending
+    uint16_t nl[BP_NLCAP];               // window offsets of every '\n', ascending
     uint8_t  bmA[8192];                  // one bit per 8-mer code: an anchor block of some sequence
     uint32_t hist[KVQ_RL_BINS / 2];      // read-length histogram, two 16-bit bins per word
-    uint32_t q1[BP_QCAP];                // candidate: read (9 bits) | position in the read << 9 (12 bits) | kind << 21
-    uint32_t q2[BP_Q2CAP];               // work item: candidate << 22 | index entry
+    union {
+        struct {
+            uint32_t q1[BP_QCAP];        // candidate: read (9 bits) | position in the read << 9 (12 bits) | kind << 21
+            uint32_t q2[BP_Q2CAP];       // work item: candidate << 22 | index entry
+        };
+        uint32_t nlp[BP_WIN / 32 + 8];   // newline plane, 1 bit per byte: lives from P0 to the newline list (P1), the queues from P3 on
+    };
     uint32_t rinfo[ST_RCAP];             // read offset in the window | rl << 16
+    __attribute__((aligned(16))) uint8_t head[BP_HEAD];   // the first bytes of the window as text (P2 looks at line starts there)
     __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];
     uint32_t longest_p1, records, fallback, n_owned, next_tile;
 };
@@ -46,6 +56,9 @@ static_assert(sizeof(BpLds) <= 40 * 1024, "four workgroups per CU: at most 40 KB
 static_assert(offsetof(BpLds, cdp) == 0, "cdp[] first");
 #define BP_LDS_GDP ((uint32_t)offsetof(BpLds, gdp))
 #define BP_LDS_BMA ((uint32_t)offsetof(BpLds, bmA))
+#define BP_LDS_NLP ((uint32_t)offsetof(BpLds, nlp))
+#define BP_LDS_HEAD ((uint32_t)offsetof(BpLds, head))
+static_assert(sizeof(uint32_t) * (BP_QCAP + BP_Q2CAP) >= sizeof(uint32_t) * (BP_WIN / 32 + 8), "the newline plane fits the queues it shares LDS with");
 
 // (the kernel's only LDS object starts at LDS address 0: checked at kernel start)
 __device__ __forceinline__ uint32_t lds_u32_at(uint32_t addr)
@@ -84,7 +97,11 @@ __device__ __forceinline__ bool seed_live_bp(GlbWords tab2, uint32_t roff, int r
 // One work item = one (candidate, index entry) pair = one diagonal of one read against one
 // sequence (the rules of verify_item in kernels_seeded.hip; the read's bytes come from global
 // memory, `text` = address of window offset 0).  Must be called by every lane of the wave.
-__device__ __forceinline__ void verify_item_bp(const HotParams &P, const BpLds &S, GlbWords tab2, GlbBytes text, bool active,
+struct BpHot {                       // what the verification needs of the parameters
+    const KvqParams *cold; GlbBytes tab; GlbWords tab2;
+    int maxerrors, minoverlap;
+};
+__device__ __forceinline__ void verify_item_bp(const BpHot &P, const BpLds &S, GlbBytes text, bool active,
                                                uint32_t rec, int p, uint32_t kind, uint64_t en, int64_t tile_fpos, int stride)
 {
     bool hitAB = false, hitC = false;
@@ -105,7 +122,7 @@ __device__ __forceinline__ void verify_item_bp(const HotParams &P, const BpLds &
         // most false candidates die here, on the first 16 bases of the diagonal: compared as 2-bit
         // codes (bytes that are equal have equal codes: this never rejects what the bytes accept)
         bool alive = L > 0;
-        if (alive && L >= 16) alive = diff_codes(cdp32(roff + (uint32_t)a), tab2_32(tab2, toff + (uint32_t)(a + d))) <= me;
+        if (alive && L >= 16) alive = diff_codes(cdp32(roff + (uint32_t)a), tab2_32(P.tab2, toff + (uint32_t)(a + d))) <= me;
         // which reference loops visit this diagonal
         bool canAB = false, canC = false;
         const bool guard = rl > mo && seql > mo;
@@ -134,14 +151,14 @@ __device__ __forceinline__ void verify_item_bp(const HotParams &P, const BpLds &
                 bool earlier = false;
                 for (int jj = 0; jj <= me && !earlier; jj++) {
                     const int ph = jj * SK, pt = rl - (jj + 1) * SK;
-                    if (ph + SK <= rl && (kind == 0u || ph < p)) earlier = seed_live_bp(tab2, roff, rl, ph, toff, seql, ph + d);
-                    if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live_bp(tab2, roff, rl, pt, toff, seql, pt + d);
+                    if (ph + SK <= rl && (kind == 0u || ph < p)) earlier = seed_live_bp(P.tab2, roff, rl, ph, toff, seql, ph + d);
+                    if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live_bp(P.tab2, roff, rl, pt, toff, seql, pt + d);
                 }
                 if (kind == 0u) {
                     for (int jj = 0; jj <= me && !earlier; jj++)
                         for (int sft = 0; sft < stride && !earlier; sft++) {
                             const int o = jj * SK + sft;
-                            if (o < q && ((o - d) & (stride - 1)) == 0) earlier = seed_live_bp(tab2, roff, rl, o - d, toff, seql, o);
+                            if (o < q && ((o - d) & (stride - 1)) == 0) earlier = seed_live_bp(P.tab2, roff, rl, o - d, toff, seql, o);
                         }
                 }
                 if (!earlier) { hitAB = canAB; hitC = canC; }
@@ -168,105 +185,204 @@ __device__ __forceinline__ void bp_vector(const uint4 v, uint32_t addk, uint32_t
     c32 = ((cc[0] | (cc[1] << 8)) >> 1) | ((cc[2] | (cc[3] << 8)) << 15);
 }
 
-#ifndef BP_PREFETCH
-#define BP_PREFETCH 0              // the next tile's text: 1 = fetched into registers one tile ahead (20 VGPRs live through the tile),
-#endif                             // 0 = fetched at the start of its tile, 2 = the same, but touched during the tile before (one dword per thread brings the lines into L2)
+// everything the kernel needs lives in one block of device memory; the kernel reads a field where it is
+// wanted (scalar loads) instead of holding thirty kernel arguments in scalar registers for the whole
+// launch: at eight waves per SIMD a wave has 80 of them, and what does not fit is kept in VGPR lanes
+struct BpArgs {
+    KvqParams P;
+    SeedTables X;
+    const uint8_t *data; int64_t fpos_base;
+    const uint4 *tiles; uint32_t *tile_report; unsigned int *tile_ctr;
+    uint32_t ntiles, tile_bytes, dbg, pad_;
+};
+typedef const __attribute__((address_space(4))) BpArgs *BpArgsPtr;
+// the block's address, opaque to the compiler from here on: loads through it are issued where they are
+// written, not hoisted to the top of the kernel
+__device__ __forceinline__ BpArgsPtr bp_args(const BpArgs *A)
+{
+    BpArgsPtr p = (BpArgsPtr)A;
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 #ifndef BP_OCC
 #define BP_OCC 8                   // waves per SIMD the kernel is built for (8: four workgroups per CU, 64 VGPRs)
 #endif
-template <int SS, bool STAMPS>
+
+// longest run of ones in the n (0..64) low bits of m (bits from n on are zero): summary of the slice
+// for the merge over lanes (first-longest-wins, workhorse.c:1062)
+__device__ __forceinline__ void bp_runs64(uint64_t m, int n, uint32_t dbg, int &pre, int &suf, int &best, int &bstart)
+{
+    const uint64_t nmask = n < 64 ? (1ull << n) - 1ull : ~0ull;
+    uint64_t zz = ~m & nmask;                                 // the bad bytes of the slice
+    const int c = __popcll(zz);
+    if (!__any(c > 3) && !(dbg & 4u)) {
+        // the usual case, at most three bad bytes in any lane's slice: their positions in closed form
+        // (first, second and last one), the runs are the four gaps between them
+        const uint32_t lo = (uint32_t)zz, hi = (uint32_t)(zz >> 32);
+        auto ctz64 = [&](uint32_t l, uint32_t h) -> uint32_t {        // n when there is no bit
+            const uint32_t pl = (uint32_t)(__ffs((int)l) - 1), ph = (uint32_t)(__ffs((int)h) - 1);
+            const uint32_t phi = ph > 0xFFFFFFDFu ? 0xFFFFFFFFu : ph + 32u;
+            uint32_t r = pl < phi ? pl : phi; return r < (uint32_t)n ? r : (uint32_t)n;
+        };
+        const uint32_t p1 = ctz64(lo, hi);
+        const uint64_t z2 = zz & (zz - 1ull);
+        const uint32_t p2 = ctz64((uint32_t)z2, (uint32_t)(z2 >> 32));
+        // one behind the last bad byte (0 when there is none)
+        const uint32_t e = hi ? 64u - (uint32_t)__clz((int)hi) : lo ? 32u - (uint32_t)__clz((int)lo) : 0u;
+        const int g0 = (int)p1, g1 = (int)p2 - (int)p1 - 1, g2 = (int)e - (int)p2 - 2, g3 = n - (int)e;
+        int bl = g0, bs = 0;
+        if (g1 > bl) { bl = g1; bs = (int)p1 + 1; }
+        if (g2 > bl) { bl = g2; bs = (int)p2 + 1; }
+        if (g3 > bl) { bl = g3; bs = (int)e; }
+        pre = g0; suf = g3; best = bl; bstart = bs;
+    } else if (!__any(c > 8) && !(dbg & 4u)) {
+        // a few more: walk them (branch-free: a lane that has run out of bad bytes sees "one at n", which closes its last run)
+        int prev = 0, first = n, p, bl = 0, bs = 0;
+        do {
+            const uint32_t plo = (uint32_t)(__ffs((int)(uint32_t)zz) - 1), ph = (uint32_t)(__ffs((int)(uint32_t)(zz >> 32)) - 1);
+            const uint32_t phi = ph > 0xFFFFFFDFu ? 0xFFFFFFFFu : ph + 32u;
+            uint32_t pm = plo < phi ? plo : phi; if (pm > (uint32_t)n) pm = (uint32_t)n;
+            p = (int)pm;
+            zz &= zz - 1ull;
+            first = first < p ? first : p;
+            const int gap = p - prev;
+            if (gap > bl) { bl = gap; bs = prev; }
+            prev = p < n ? p + 1 : prev;
+        } while (__any(p < n));
+        pre = first; suf = n - prev; best = bl; bstart = bs;
+    } else {
+        const uint64_t inv = ~m;
+        pre = inv ? __ffsll((long long)inv) - 1 : 64; if (pre > n) pre = n;
+        const uint64_t top = ~(m << (64 - n));                 // leading ones of the n-bit mask = trailing run
+        suf = top ? __clzll((long long)top) : 64; if (suf > n) suf = n;
+        longest_run64(m, n, best, bstart);
+    }
+}
+
+// LG >= 0: the lane group of a read is 1 << LG lanes wide whatever the tile holds (a tile with more than
+// 512 >> LG reads takes several passes); LG < 0: the widest group that gives every read of the tile its
+// own lanes in one pass, worked out per tile.  The launch picks LG = 2 when that is what the records of
+// the text ask for (100 to 250 bases), the general kernel otherwise.
+template <int SS, int LG, bool STAMPS>
 __global__ void __launch_bounds__(ST_THREADS, BP_OCC)
-kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__restrict__ data, int64_t fpos_base,
-            const uint4 *__restrict__ tiles, uint32_t ntiles, uint32_t *__restrict__ tile_report, uint32_t dbg,
-            uint32_t tile_bytes, unsigned int *__restrict__ tile_ctr)
+kvq_scan_bp(const BpArgs *__restrict__ A_)
 {
     __shared__ __align__(16) BpLds S;
     uint8_t *const lds_raw = reinterpret_cast<uint8_t *>(&S);
     int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = rfl((uint32_t)tid >> 6);
     if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t *)lds_raw) != 0u) __builtin_trap();   // lds_u32_at
-    const bool younger = wave >= 4u;
-    HotParams P;
-    P.cold = Pg; P.tab = (GlbBytes)Pg->tab; P.maxerrors = Pg->maxerrors; P.minoverlap = Pg->minoverlap;
-    P.minreadlength = Pg->minreadlength; P.amin = Pg->amin;
-    const GlbWords tab2 = (GlbWords)X.tab2;
-    const __attribute__((address_space(1))) uint8_t *const bmL = (const __attribute__((address_space(1))) uint8_t *)X.bm1 + 8192;
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_t = 0, wave_p34 = 0;
 #define BSTAMP(i) do { if constexpr (STAMPS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
 
-    for (int i = tid; i < 2048; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = X.bm1[i];
+    uint32_t ntiles, tile_bytes, dbg, amin;
+    {
+        const BpArgsPtr A = bp_args(A_);
+        ntiles = A->ntiles; tile_bytes = A->tile_bytes; dbg = A->dbg; amin = (uint32_t)A->P.amin;
+        const GlbWords bm1 = (GlbWords)A->X.bm1;
+        for (int i = tid; i < 2048; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = bm1[i];
+        if (tid == 0) S.next_tile = atomicAdd(A->tile_ctr, 1u);
+    }
     for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) S.hist[i] = 0;
     if (tid == 0) { S.longest_p1 = 0; S.records = 0; S.fallback = 0; }
     if (tid < 8) { S.cdp[BP_WIN / 16 + tid] = 0; S.gdp[BP_WIN / 32 + tid] = 0; }    // slack behind the planes
 
     static_assert(ST_ROUNDS * 16u == ST_BLK, "one scan block per thread");
     static_assert(ST_WAVES == 8, "eight wave totals");
-    uint4 pre[ST_ROUNDS];
-    const uint32_t blk = (uint32_t)tid * ST_BLK;                           // the block's place in the window
-    const uint32_t toff = blk - ST_PRE;                                    // ... and in the tile's text (tid >= 1)
-    const uint32_t vo = tid ? toff : ST_NO_BLOCK;
-    if (BP_PREFETCH == 1 && blockIdx.x < ntiles) {
-        const TileGeo J = tile_geo(blockIdx.x, tiles, tile_bytes);
-        tile_load80(data, J.load_lo, J.load_hi, vo, pre);
-    }
-    if (tid == 0) S.next_tile = atomicAdd(tile_ctr, 1u);
+    // The tile's text travels HBM -> registers -> planes.  The loads are coalesced: wave w covers the
+    // window bytes [5120 w, 5120 (w + 1)), in round r lane l takes vector (16 bytes) 320 w + 64 r + l
+    // of the window, so one load instruction of a wave fetches 1 KiB of consecutive text.  A vector's
+    // three plane pieces (16 newline bits, 16 good bits, 32 code bits) go to its place in the planes;
+    // the newline list then needs every thread's own 80 consecutive newline bits: thread t re-reads
+    // bits [80 t, 80 t + 80) of the newline plane, which its own wave has written.
     __syncthreads();
 
-    const uint32_t addk = (uint32_t)(0x80 - P.amin) * 0x01010101u;
+    const uint32_t addk = (0x80u - amin) * 0x01010101u;
     uint32_t tiles_done = 0;
     uint32_t gn = rfl(S.next_tile);
     for (uint32_t g = blockIdx.x; g < ntiles; ) {
-        const TileGeo J = tile_geo(g, tiles, tile_bytes);
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
+        const uint32_t blk = (uint32_t)tid * ST_BLK;                           // the thread's newline block in the window
+        const uint32_t wv = wave * (ST_BLK * 64u / 16u) + (uint32_t)lane;      // the lane's vector of round 0
         if constexpr (STAMPS) stamp_t = __builtin_amdgcn_s_memtime();
-        if (BP_PREFETCH != 1) tile_load80(data, J.load_lo, J.load_hi, vo, pre);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0)
-
-        // ---- P0: registers -> planes and newline flags of the thread's block; the next tile's loads go out ----
-        const uint32_t own_end_l = J.own_end - J.g0 + ST_PRE;              // ownership ends here
-        const uint32_t end_l = J.load_hi - J.g0 + ST_PRE;                  // end of the loaded text
-        const GlbBytes text = (GlbBytes)data + J.g0 - ST_PRE;              // window offset 0 (never read below ST_PRE)
-        uint32_t nlw[ST_ROUNDS];
-        const uint32_t blk_lo = J.g0 + toff;
-        // only the block with the chunk's first byte (when that is not 16-byte aligned) and the block with
-        // its last byte need masks: their wave zeroes the bytes outside [own_begin, load_hi) in place
-        // (rare: the straight-line code below never sees it)
-        const bool edge = tid && (blk_lo < J.own_begin || (blk_lo < J.load_hi && J.load_hi < blk_lo + ST_BLK && (J.load_hi & 15u)));
-        if (__any(edge)) {
+        // tile geometry (the per-tile table kvq_expand_tiles wrote: chunk begin, chunk end, tile number)
+        uint32_t Ja, Jb, Jt, g0; GlbBytes text;
+        uint4 pre[ST_ROUNDS];
+        {
+            const BpArgsPtr A = bp_args(A_);
+            // (diagnostic 64: every tile scans the text of one of the first 64 tiles -- the same work from L2 instead of HBM; results are wrong)
+            const u32x4_t q = ((const __attribute__((address_space(4))) u32x4_t *)A->tiles)[(dbg & 64u) ? (g & 63u) : g];
+            Ja = q.x; Jb = q.y; Jt = q.z;
+            g0 = (Ja & ~15u) + Jt * tile_bytes;
+            const uint8_t *const data = A->data;
+            text = (GlbBytes)data + g0 - ST_PRE;                               // window offset 0 (never read below ST_PRE)
+            const uint32_t load_hi = g0 + ST_TILE + ST_OV < Jb ? g0 + ST_TILE + ST_OV : Jb;
+            // byte offset of the lane's vectors in the tile's text (the window starts ST_PRE bytes in front of
+            // the text: vectors 0..4 never hold text, an offset beyond any tile makes their load return zeros;
+            // all of the offset in the checked part: the range check leaves the scalar offset out)
+            const uint32_t vo = 16u * wv - ST_PRE, vo0 = wv >= ST_PRE / 16u ? vo : ST_NO_BLOCK;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(data + g0), 0, (int)(((load_hi + 15u) & ~15u) - g0), 0x00020000);
 #pragma unroll
             for (int r = 0; r < (int)ST_ROUNDS; r++) {
-                const uint32_t gp = blk_lo + 16u * r;
-                uint32_t x[4] = { pre[r].x, pre[r].y, pre[r].z, pre[r].w };
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(r ? vo + 1024u * r : vo0), 0, 0);
+                pre[r] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
+        const uint32_t own_end = g0 + tile_bytes < Jb ? g0 + tile_bytes : Jb;
+        const uint32_t load_hi = g0 + ST_TILE + ST_OV < Jb ? g0 + ST_TILE + ST_OV : Jb;
+        const uint32_t own_begin_l = (Jt == 0 ? Ja : g0) - g0 + ST_PRE;       // window offsets: first owned byte,
+        const uint32_t own_end_l = own_end - g0 + ST_PRE;                     // ownership ends here,
+        const uint32_t end_l = load_hi - g0 + ST_PRE;                         // end of the loaded text
+
+        // ---- P0: registers -> planes; the thread's 80 newline flags ----
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
+        // bytes in front of the chunk's first byte (when that is not 16-byte aligned) and behind its last
+        // one are zeroed in place by the wave whose stretch holds them (rare: scalar test)
+        {
+            const uint32_t w_lo = wave * (ST_BLK * 64u), w_hi = w_lo + ST_BLK * 64u;
+            const bool cut = ((own_begin_l & 15u) && own_begin_l > w_lo && own_begin_l < w_hi) || ((end_l & 15u) && end_l > w_lo && end_l < w_hi);
+            if (cut) {
+                uint32_t wv_ = wv;
+                asm volatile("" : "+v"(wv_));                               // (worked out here, not hoisted out of the tile loop into twenty spilled registers)
 #pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const uint32_t keep = (tid && gp < J.load_hi) ? kvq_range_flags(gp + 4u * d, J.own_begin, J.load_hi) : 0u;   // 0x80 per byte inside
-                    x[d] &= (keep >> 7) * 0xFFu;
+                for (int r = 0; r < (int)ST_ROUNDS; r++) {
+                    const uint32_t o = 16u * (wv_ + 64u * r);               // window offset of the vector
+                    uint32_t x[4] = { pre[r].x, pre[r].y, pre[r].z, pre[r].w };
+#pragma unroll
+                    for (int d = 0; d < 4; d++) x[d] &= (kvq_range_flags(o + 4u * d, own_begin_l, end_l) >> 7) * 0xFFu;
+                    pre[r] = make_uint4(x[0], x[1], x[2], x[3]);
                 }
-                pre[r] = make_uint4(x[0], x[1], x[2], x[3]);
             }
         }
         KVQ_MARK("P0 vectors");
         {
-            const uint32_t ga = BP_LDS_GDP + 10u * (uint32_t)tid, ca = 20u * (uint32_t)tid;
+            const uint32_t pa = 2u * wv, ca = 4u * wv;
 #pragma unroll
             for (int r = 0; r < (int)ST_ROUNDS; r++) {
-                uint32_t g16, c32;
-                bp_vector(pre[r], addk, nlw[r], g16, c32);
-                *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(ga + 2u * r)) = (uint16_t)g16;
-                *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(ca + 4u * r)) = c32;
+                uint32_t n16, g16, c32;
+                bp_vector(pre[r], addk, n16, g16, c32);
+                *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(BP_LDS_NLP + pa + 128u * r)) = (uint16_t)n16;
+                *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(BP_LDS_GDP + pa + 128u * r)) = (uint16_t)g16;
+                *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(ca + 256u * r)) = c32;
+            }
+            // the head of the window as text, for P2 (wave 0 holds it)
+            if (wave == 0u) {
+#pragma unroll
+                for (int r = 0; r < (int)(BP_HEAD / 1024u); r++)
+                    *reinterpret_cast<__attribute__((address_space(3))) u32x4_t *>((uintptr_t)(BP_LDS_HEAD + 16u * (uint32_t)lane + 1024u * r)) = u32x4_t{ pre[r].x, pre[r].y, pre[r].z, pre[r].w };
             }
         }
         KVQ_MARK("P0 vectors end");
-        // the flags are worked out before the registers are handed to the next tile's loads (left alone
-        // the compiler issues the loads first and keeps a copy of all twenty dwords to do the flags later)
-        __builtin_amdgcn_sched_barrier(0);
-        if (BP_PREFETCH == 1 && gn < ntiles) {
-            const TileGeo N = tile_geo(gn, tiles, tile_bytes);
-            tile_load80(data, N.load_lo, N.load_hi, vo, pre);
+        // this thread's 80 newline bits: bits [80 t, 80 t + 80) of the newline plane = its bytes 10 t ..
+        uint32_t m0, m1, m2;
+        {
+            const uint32_t a = BP_LDS_NLP + ((10u * (uint32_t)tid) & ~3u), sh = ((uint32_t)tid & 1u) * 16u;
+            const uint32_t d0 = lds_u32_at(a), d1 = lds_u32_at(a + 4u), d2 = lds_u32_at(a + 8u);
+            m0 = __builtin_amdgcn_alignbit(d1, d0, sh); m1 = __builtin_amdgcn_alignbit(d2, d1, sh); m2 = (d2 >> sh) & 0xFFFFu;
         }
         static_assert(ST_BLK == 80u, "five vectors per block");
-        uint32_t m0 = nlw[0] | (nlw[1] << 16), m1 = nlw[2] | (nlw[3] << 16), m2 = nlw[4];
         const uint32_t cnt = (uint32_t)(__popc(m0) + __popc(m1) + __popc(m2));
         const uint32_t incl = kvq_wave_incl_scan(cnt);
         if (lane == 63) S.wtot[wave] = incl;
@@ -291,7 +407,7 @@ kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__res
                     const uint32_t w = in0 ? m0 : in1 ? m1 : m2;
                     if (w) {
                         const uint32_t pos = blk + (in0 ? 0u : in1 ? 32u : 64u) + (uint32_t)(__ffs((int)w) - 1);
-                        if (n < ST_NLCAP) S.nl[n] = (uint16_t)pos;
+                        if (n < BP_NLCAP) S.nl[n] = (uint16_t)pos;
                         n++;
                         const uint32_t w1 = w & (w - 1u);
                         if (in0) m0 = w1; else if (in1) m1 = w1; else m2 = w1;
@@ -302,23 +418,26 @@ kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__res
         __syncthreads();
         KVQ_MARK("P1b end / P2");
         BSTAMP(2);
-        uint32_t drawn = 0;
-        if (tid == ST_THREADS - 64) drawn = atomicAdd(tile_ctr, 1u);
 
         // ---- P2 (every wave, redundantly): which records does this tile own? ----
-        uint32_t nrec = 0, jn = TR_NONE;
+        uint32_t nrec = 0, jn = TR_NONE, drawn = 0;
         {
-            const uint32_t n_nl = n_all < ST_NLCAP ? n_all : ST_NLCAP;
+            const uint32_t n_nl = n_all < BP_NLCAP ? n_all : BP_NLCAP;
             const uint32_t n_owned = rfl(S.n_owned);
-            uint32_t fallback = n_all > ST_NLCAP ? 1u : 0u;
-            if (J.t == 0) jn = 0;                                            // chunk start: exact
+            uint32_t fallback = n_all > BP_NLCAP ? 1u : 0u;
+            if (Jt == 0) jn = 0;                                            // chunk start: exact
             else {
                 const uint32_t m = (uint32_t)lane;
                 bool ok = false;
                 if (m >= 1 && m <= 8 && m <= n_owned && m + 2 <= n_nl) {
                     const uint32_t ls0 = (uint32_t)S.nl[m - 1] + 1u;
                     const uint32_t ls2 = (uint32_t)S.nl[m + 1] + 1u;
-                    ok = ls0 < end_l && ls2 < end_l && text[ls0] == '@' && text[ls2] == '+';
+                    if (ls0 < end_l && ls2 < end_l) {
+                        // (line starts inside the head of the window are looked up in LDS; further on, rare, in global memory)
+                        const uint32_t c0 = ls0 < BP_HEAD ? lds_byte_at(BP_LDS_HEAD + ls0) : (uint32_t)text[ls0];
+                        const uint32_t c2 = ls2 < BP_HEAD ? lds_byte_at(BP_LDS_HEAD + ls2) : (uint32_t)text[ls2];
+                        ok = c0 == '@' && c2 == '+';
+                    }
                 }
                 const uint64_t mk = __ballot(ok);
                 if (mk) jn = (uint32_t)(__ffsll((long long)mk) - 1);
@@ -327,49 +446,50 @@ kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__res
                 if (jn <= n_owned) nrec = (n_owned - jn) / 4u + 1u;
                 if (nrec > 0 && jn + 4u * nrec > n_nl) {
                     const uint32_t fit = n_nl >= jn ? (n_nl - jn) / 4u : 0u;
-                    if (J.load_hi < J.b || n_all > ST_NLCAP) fallback = 1u;
+                    if (load_hi < Jb || n_all > BP_NLCAP) fallback = 1u;
                     nrec = fit;
                 }
                 if (nrec > ST_RCAP) { nrec = ST_RCAP; fallback = 1u; }
             }
-            if (tid == 0) {
-                tile_report[g] = (n_owned & 0xFFFFu) | ((jn & 0xFFu) << 16) | (fallback ? TR_FLAG_FALLBACK : 0u);
-                S.records += nrec;
+            // thread 0 reports; the last wave (which holds the fewest reads) draws the tile after next: wanted
+            // at the end of this tile, and the answer is not waited for before that
+            if (tid == 0 || tid == ST_THREADS - 64) {
+                const BpArgsPtr A = bp_args(A_);
+                if (tid == 0) {
+                    A->tile_report[g] = (n_owned & 0xFFFFu) | ((jn & 0xFFu) << 16) | (fallback ? TR_FLAG_FALLBACK : 0u);
+                    S.records += nrec;
+                } else drawn = atomicAdd(A->tile_ctr, 1u);
             }
         }
 
-        uint32_t touch = 0;
-        if (BP_PREFETCH == 2 && gn < ntiles) {
-            // one dword of every 80 bytes of the next tile: its lines are in L2 when the loads at the end of this tile ask for them
-            const TileGeo N = tile_geo(gn, tiles, tile_bytes);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(data + N.load_lo), 0, (int)(((N.load_hi + 15u) & ~15u) - N.load_lo), 0x00020000);
-            touch = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, 0, 0);
-        }
         if (dbg & 32u) nrec = 0;                                     // diagnostic: front end only
         KVQ_MARK("P2 end / P3 setup");
         BSTAMP(3);
-        if (younger) KVQ_SETPRIO(2); else KVQ_SETPRIO(1);
+        if (wave >= 4u) KVQ_SETPRIO(2); else KVQ_SETPRIO(1);
         unsigned long long wave_t3 = 0;
         if constexpr (STAMPS) wave_t3 = __builtin_amdgcn_s_memtime();
         // ---- P3 / P4 passes: reads -> candidates, then candidates -> hits ----
-        const int64_t tile_fpos = fpos_base + (int64_t)J.g0;
+        // G lanes share one read, a wave owns its 64/G reads from here to the end of the tile
         static_assert(ST_THREADS == 512, "lg = 9 - ceil(log2(nrec))");
-        const int lg_ = 9 - (nrec > 1u ? 32 - __builtin_clz(nrec - 1u) : 0);
-        const uint32_t lg = lg_ < 0 ? 0u : lg_ > 6 ? 6u : (uint32_t)lg_;
+        uint32_t lg;
+        if constexpr (LG >= 0) lg = (uint32_t)LG;
+        else {
+            const int lg_ = 9 - (nrec > 1u ? 32 - __builtin_clz(nrec - 1u) : 0);
+            lg = lg_ < 0 ? 0u : lg_ > 6 ? 6u : (uint32_t)lg_;
+        }
         const uint32_t G = 1u << lg, RP = ST_THREADS >> lg;
         const uint32_t gl = (uint32_t)tid & (G - 1u), gr = (uint32_t)tid >> lg;
         for (uint32_t pass0 = 0; pass0 < nrec; pass0 += RP) {
             const uint32_t k = pass0 + gr;
             const bool have = k < nrec;
             uint32_t roff = 0; int rl = 0;
+            uint32_t c0 = '@', cp = '+';                            // the record's '@' and '+' (1037-1048): fetched here, looked at behind the pass
             if (have) {
                 const uint32_t m = jn + 4u * k;
-                const uint32_t rstart = m == 0 ? ST_PRE + (J.a - (J.a & ~15u)) : (uint32_t)S.nl[m - 1] + 1u;
+                const uint32_t rstart = m == 0 ? ST_PRE + (Ja & 15u) : (uint32_t)S.nl[m - 1] + 1u;
                 const uint32_t n0 = S.nl[m], n1 = S.nl[m + 1], n2 = S.nl[m + 2], n3 = S.nl[m + 3];
                 const uint32_t sread = n0 + 1u, plus = n1 + 1u, sscore = n2 + 1u;
         KVQ_MARK("trim");
-                // the record's '@' and '+' (1037-1048) from global memory, looked at behind the trim
-                uint32_t c0 = '@', cp = '+';
                 if (gl == 0) { c0 = text[rstart]; cp = text[plus]; }
                 // quality trim (1055-1068): this lane's slice of the score line is a bit range of the good plane
                 const int Q = (int)(n3 - sscore);                   // the closing '\n' is implied
@@ -385,33 +505,11 @@ kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__res
                         const uint32_t a = BP_LDS_GDP + ((bit >> 5) << 2), sh = bit & 31u;
                         const uint32_t d0 = lds_u32_at(a), d1 = lds_u32_at(a + 4u), d2 = lds_u32_at(a + 8u);
                         const uint64_t nmask = n < 64 ? (1ull << n) - 1ull : ~0ull;
-                        const uint64_t m = (((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh)) & nmask;
+                        const uint64_t mm = (((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh)) & nmask;
                         Seg sub; sub.beg = c0_; sub.len = n;
-                        int bl, bs;
-                        uint64_t zz = ~m & nmask;                          // the bad bytes of the slice
-                        if (!__any(__popcll(zz) > 4) && !(dbg & 4u)) {
-                            // the usual case, few bad bytes in any lane's slice: walk them (runs = the gaps between them)
-                            int prev = 0, first = n, p; bl = 0; bs = 0;
-                            do {
-                                const uint32_t plo = (uint32_t)(__ffs((int)(uint32_t)zz) - 1), ph = (uint32_t)(__ffs((int)(uint32_t)(zz >> 32)) - 1);
-                                const uint32_t phi = ph > 0xFFFFFFDFu ? 0xFFFFFFFFu : ph + 32u;
-                                uint32_t pm = plo < phi ? plo : phi; if (pm > (uint32_t)n) pm = (uint32_t)n;
-                                p = (int)pm;
-                                zz &= zz - 1ull;
-                                first = first < p ? first : p;
-                                const int gap = p - prev;
-                                if (gap > bl) { bl = gap; bs = prev; }
-                                prev = p < n ? p + 1 : prev;
-                            } while (__any(p < n));
-                            sub.pre = first; sub.suf = n - prev;
-                        } else {
-                            const uint64_t inv = ~m;
-                            sub.pre = inv ? __ffsll((long long)inv) - 1 : 64; if (sub.pre > n) sub.pre = n;
-                            const uint64_t top = ~(m << (64 - n));         // leading ones of the n-bit mask = trailing run
-                            sub.suf = top ? __clzll((long long)top) : 64; if (sub.suf > n) sub.suf = n;
-                            longest_run64(m, n, bl, bs);
-                        }
-                        sub.best = bl; sub.bstart = c0_ + bs;
+                        int bs;
+                        bp_runs64(mm, n, dbg, sub.pre, sub.suf, sub.best, bs);
+                        sub.bstart = c0_ + bs;
                         return sub;
                     };
                     if (!__any(per > 64)) sg = round(sg.beg);
@@ -451,8 +549,6 @@ kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__res
                     roff = sread + (uint32_t)__shfl(sg.bstart, lane & ~(int)(G - 1u), 64);             // 1070
                 }
                 if (gl == 0) {
-                    if (c0 != '@') atomicMin(Pg->err, ((unsigned long long)(tile_fpos + rstart - ST_PRE) << 16) | (0ull << 8) | c0);
-                    else if (cp != '+') atomicMin(Pg->err, ((unsigned long long)(tile_fpos + plus - ST_PRE) << 16) | (1ull << 8) | cp);
                     if (rl < KVQ_RL_BINS) atomicAdd(&S.hist[rl >> 1], 1u << (16 * (rl & 1)));          // 394-402
                     atomicMax(&S.longest_p1, (uint32_t)(rl + 1));
                     S.rinfo[k] = roff | ((uint32_t)rl << 16);
@@ -468,7 +564,13 @@ kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__res
             uint32_t *const q1 = S.q1 + wave * BP_QW; uint32_t *const q2 = S.q2 + wave * BP_Q2W;
             uint32_t sub = 0, step = rpw;
             while (sub < npass) {
-                const bool mine = have && rl >= P.minreadlength && !(dbg & 2u) && grw >= sub && grw - sub < step;       // 1100
+                int minrl, me_; const __attribute__((address_space(1))) uint8_t *bmL;
+                {
+                    const BpArgsPtr A = bp_args(A_);
+                    minrl = A->P.minreadlength; me_ = A->P.maxerrors;
+                    bmL = (const __attribute__((address_space(1))) uint8_t *)A->X.bm1 + 8192;
+                }
+                const bool mine = have && rl >= minrl && !(dbg & 2u) && grw >= sub && grw - sub < step;       // 1100
                 uint32_t qn = 0;
                 int e0 = 0, e1 = 0;
                 if (mine) {
@@ -477,7 +579,6 @@ kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__res
                     e0 = (int)mul_u24(gl, (uint32_t)per); if (e0 > NPe) e0 = NPe;
                     e1 = e0 + per; if (e1 > NPe) e1 = NPe;
                 }
-                const int me_ = P.maxerrors;
                 // is the 8-mer at read position pp anywhere in a sequence?  (bitmap of all sequence 8-mers: global memory)
                 auto fixed_block = [&](int pp, bool ok) -> bool {
                     const uint32_t code = cdp_code8(roff + (uint32_t)(ok ? pp : 0));
@@ -562,13 +663,22 @@ kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__res
                 const bool over1 = qn > BP_QW;                            // candidates were dropped
                 const uint32_t qn_ok = (over1 || (dbg & 1u)) ? 0u : qn;
                 uint32_t q2n = 0;
+                BpHot H = {}; GlbWords start_anc = nullptr, start_all = nullptr; const __attribute__((address_space(1))) uint64_t *ent_anc = nullptr, *ent_all = nullptr;
+                int64_t tile_fpos = 0;
+                if (qn_ok) {
+                    const BpArgsPtr A = bp_args(A_);
+                    H.cold = &A_->P; H.tab = (GlbBytes)A->P.tab; H.tab2 = (GlbWords)A->X.tab2; H.maxerrors = me_; H.minoverlap = A->P.minoverlap;
+                    start_anc = (GlbWords)A->X.start_anc; start_all = (GlbWords)A->X.start_all;
+                    ent_anc = (const __attribute__((address_space(1))) uint64_t *)A->X.ent_anc; ent_all = (const __attribute__((address_space(1))) uint64_t *)A->X.ent_all;
+                    tile_fpos = A->fpos_base + (int64_t)g0;
+                }
                 for (uint32_t q0 = 0; q0 < qn_ok; q0 += 64u) {
                     const uint32_t qi = q0 + lane;
                     uint32_t en0 = 0, ne = 0;
                     if (qi < qn_ok) {
                         const uint32_t cd = q1[qi];
                         const uint32_t code = cdp_code8((S.rinfo[cd & 511u] & 0xFFFFu) + ((cd >> 9) & 4095u));
-                        const uint32_t *st = (cd >> 21) ? X.start_all : X.start_anc;
+                        const GlbWords st = (cd >> 21) ? start_all : start_anc;
                         en0 = st[code]; ne = st[code + 1u] - en0;
                     }
                     const uint32_t inc = kvq_wave_incl_scan(ne);
@@ -593,40 +703,48 @@ kvq_scan_bp(const KvqParams *__restrict__ Pg, SeedTables X, const uint8_t *__res
                             const uint32_t it = q2[ii];
                             const uint32_t cd = q1[it >> 22];
                             rec = cd & 511u; p = (int)((cd >> 9) & 4095u); kind = cd >> 21;
-                            en = (kind ? X.ent_all : X.ent_anc)[it & 0x3FFFFFu];
+                            en = (kind ? ent_all : ent_anc)[it & 0x3FFFFFu];
                         }
-                        verify_item_bp(P, S, tab2, text, active, rec, p, kind, en, tile_fpos, SS);
+                        verify_item_bp(H, S, text, active, rec, p, kind, en, tile_fpos, SS);
                     }
                 }
                 KVQ_SETPRIO(2);
                 sub += step;
             }
             KVQ_SETPRIO(0);
+            // the '@' / '+' checks of the pass's records (the bytes have come back long ago)
+            if (have && gl == 0 && (c0 != '@' || cp != '+')) {
+                const BpArgsPtr A = bp_args(A_);
+                const uint32_t m = jn + 4u * k;
+                const uint32_t rstart = m == 0 ? ST_PRE + (Ja & 15u) : (uint32_t)S.nl[m - 1] + 1u, plus = (uint32_t)S.nl[m + 1] + 1u;
+                const int64_t tf = A->fpos_base + (int64_t)g0;
+                if (c0 != '@') atomicMin(A->P.err, ((unsigned long long)(tf + rstart - ST_PRE) << 16) | (0ull << 8) | c0);
+                else atomicMin(A->P.err, ((unsigned long long)(tf + plus - ST_PRE) << 16) | (1ull << 8) | cp);
+            }
         KVQ_MARK("P4 end");
             BSTAMP(6);
         }
         if constexpr (STAMPS) wave_p34 += __builtin_amdgcn_s_memtime() - wave_t3;
-        if (BP_PREFETCH == 2) asm volatile("" :: "v"(touch));       // (the touch has come back long ago; this only keeps it alive)
         // everyone is done with the tile's planes before the next tile's fill
         if (tid == ST_THREADS - 64) S.next_tile = drawn;
         __syncthreads();
         KVQ_MARK("tile end");
         BSTAMP(7);
-        if (tid == 0 && S.fallback) { atomicOr(&tile_report[g], TR_FLAG_FALLBACK); S.fallback = 0; }
+        if (tid == 0 && S.fallback) { atomicOr(&bp_args(A_)->tile_report[g], TR_FLAG_FALLBACK); S.fallback = 0; }
         g = gn; gn = rfl(S.next_tile);
         if (++tiles_done == ST_HIST_TILES) {
+            unsigned long long *const ctr = bp_args(A_)->P.ctr;
             for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) {
                 const uint32_t w = S.hist[i];
-                if (w & 0xFFFFu) atomicAdd(&Pg->ctr[KVQ_CTR_RL_ + 2 * i], (unsigned long long)(w & 0xFFFFu));
-                if (w >> 16) atomicAdd(&Pg->ctr[KVQ_CTR_RL_ + 2 * i + 1], (unsigned long long)(w >> 16));
+                if (w & 0xFFFFu) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i], (unsigned long long)(w & 0xFFFFu));
+                if (w >> 16) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i + 1], (unsigned long long)(w >> 16));
                 S.hist[i] = 0;
             }
-            tiles_done = 0;
-            __syncthreads();
+            tiles_done = 0;      // (the next updates of the histogram lie behind the next tile's barriers)
         }
     }
 
-    unsigned long long *const ctr = Pg->ctr;
+    unsigned long long *const ctr = bp_args(A_)->P.ctr;
     if constexpr (STAMPS) {
         if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
         if (lane == 0) atomicAdd(&ctr[KVQ_CTR_RL_ + 908 + wave], wave_p34);
@@ -660,7 +778,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         std::vector<uint8_t> head(n);
         KVQ_HIP(hipStreamSynchronize(s->stream));
         KVQ_HIP(hipMemcpy(head.data(), d_data, n, hipMemcpyDeviceToHost));
-        s->tile_bytes = kvq_tile_for_text(head.data(), n);
+        s->tile_bytes = kvq_tile_for_text(head.data(), n, &s->rec_bytes);
     }
     const uint32_t TILE = s->tile_bytes;
     uint64_t nt = 0;
@@ -677,7 +795,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     }
     // first tile of every chunk, then the parameter block: one copy
     const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
-    const size_t first_at = s->pool.take(first_b + sizeof(KvqParams) + 16);      // ... and the tile counter behind it
+    const size_t first_at = s->pool.take(first_b + sizeof(BpArgs) + 16);         // ... and the tile counter behind it
     const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 4);
     uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
     uint64_t acc = 0;
@@ -687,37 +805,61 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         acc += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
     }
     first[nchunks] = (uint32_t)acc;
-    memcpy(s->pool.h + first_at + first_b, &P, sizeof(KvqParams));
+    static const uint32_t dbg = (uint32_t)(getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0);
     const uint32_t grid_seeded = (uint32_t)std::min<uint64_t>(nt, grid_cap);
-    memcpy(s->pool.h + first_at + first_b + sizeof(KvqParams), &grid_seeded, 4);           // tiles below this number are the workgroups' first
     uint32_t *d_first = reinterpret_cast<uint32_t *>(s->pool.d + first_at);
-    const KvqParams *d_params = reinterpret_cast<const KvqParams *>(s->pool.d + first_at + first_b);
+    const BpArgs *d_args = reinterpret_cast<const BpArgs *>(s->pool.d + first_at + first_b);
+    const KvqParams *d_params = &d_args->P;
     uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
     uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
-    // chunk offsets (run_batch put them right in front), first tiles, parameters, tile counter: one transfer
-    KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, first_at + first_b + sizeof(KvqParams) + 16 - s->cur_co_at,
+    unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + first_at + first_b + sizeof(BpArgs));
+    {
+        // the argument block of the scan kernel (kvq_scan_seeded reads its first member, the parameters)
+        BpArgs a;
+        memset(&a, 0, sizeof(a));
+        a.P = P; a.X = ix->dev; a.data = d_data; a.fpos_base = fpos_base;
+        a.tiles = reinterpret_cast<const uint4 *>(d_tchunk); a.tile_report = d_report; a.tile_ctr = d_tile_ctr;
+        a.ntiles = (uint32_t)nt; a.tile_bytes = TILE; a.dbg = dbg;
+        memcpy(s->pool.h + first_at + first_b, &a, sizeof(a));
+    }
+    memcpy(s->pool.h + first_at + first_b + sizeof(BpArgs), &grid_seeded, 4);              // tiles below this number are the workgroups' first
+    // chunk offsets (run_batch put them right in front), first tiles, arguments, tile counter: one transfer
+    KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, first_at + first_b + sizeof(BpArgs) + 16 - s->cur_co_at,
                            hipMemcpyHostToDevice, s->stream));
-    unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + first_at + first_b + sizeof(KvqParams));
     hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
 
     typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t, unsigned int *);
-    static const SeededKernel kernels[12] = { kvq_scan_bp<2, false>, kvq_scan_bp<4, false>, kvq_scan_bp<8, false>,
-                                              kvq_scan_bp<2, true>, kvq_scan_bp<4, true>, kvq_scan_bp<8, true>,
-                                              kvq_scan_seeded<2, false>, kvq_scan_seeded<4, false>, kvq_scan_seeded<8, false>,
-                                              kvq_scan_seeded<2, true>, kvq_scan_seeded<4, true>, kvq_scan_seeded<8, true> };
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (int i = 6; i < 12; i++)
-            KVQ_HIP(hipFuncSetAttribute((const void *)kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
-        attr_set = true;
-    }
-    static const uint32_t dbg = (uint32_t)(getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0);
-    {
-        const uint32_t grid = grid_seeded;
-        const SeededKernel kern = kernels[(ix->variant ? 6 : 0) + (ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0) + ((dbg & 16u) ? 3 : 0)];
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(ST_THREADS), 0, s->stream, d_params, ix->dev, d_data, fpos_base,
+    typedef void (*BpKernel)(const BpArgs *);
+    const int si = ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0, st = (dbg & 16u) ? 3 : 0;
+    if (ix->variant) {
+        static const SeededKernel kernels[6] = { kvq_scan_seeded<2, false>, kvq_scan_seeded<4, false>, kvq_scan_seeded<8, false>,
+                                                 kvq_scan_seeded<2, true>, kvq_scan_seeded<4, true>, kvq_scan_seeded<8, true> };
+        static bool attr_set = false;
+        if (!attr_set) {
+            for (SeededKernel kf : kernels)
+                KVQ_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kernels[si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_params, ix->dev, d_data, fpos_base,
                            reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg, TILE, d_tile_ctr);
+    } else {
+        // the lane group of a read: four lanes, fixed at compile time, when that is the widest power of two
+        // that gives every read of a full tile its own lanes (records of 100 to 250 bases); otherwise the
+        // kernel that works the width out per tile
+        static const BpKernel kernels[12] = { kvq_scan_bp<2, -1, false>, kvq_scan_bp<4, -1, false>, kvq_scan_bp<8, -1, false>,
+                                              kvq_scan_bp<2, -1, true>, kvq_scan_bp<4, -1, true>, kvq_scan_bp<8, -1, true>,
+                                              kvq_scan_bp<2, 2, false>, kvq_scan_bp<4, 2, false>, kvq_scan_bp<8, 2, false>,
+                                              kvq_scan_bp<2, 2, true>, kvq_scan_bp<4, 2, true>, kvq_scan_bp<8, 2, true> };
+        static const int lg_env = getenv("KVQ_LG") ? atoi(getenv("KVQ_LG")) : -2;
+        int lg = -1;
+        if (s->rec_bytes >= 40u) {
+            const uint32_t n_full = TILE / s->rec_bytes + 1u;                    // records a full tile can own
+            if (n_full <= 128u && n_full > 64u) lg = 2;
+        }
+        if (lg_env >= -1) lg = lg_env == 2 ? 2 : -1;
+        hipLaunchKernelGGL(kernels[(lg == 2 ? 6 : 0) + si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
     }
+    if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                        d_first, d_report, s->cur_fail);
     KVQ_HIP(hipGetLastError());

@@ -473,7 +473,7 @@ __device__ __forceinline__ void tile_load80(const uint8_t *data, uint32_t lo, ui
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(data + lo), 0, (int)(((hi + 15u) & ~15u) - lo), 0x00020000);
 #pragma unroll
     for (int r = 0; r < (int)ST_ROUNDS; r++) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, 16 * r, 0);       // (the 16 r as scalar offset: an inline constant)
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo + 16u * (uint32_t)r), 0, 0);
         pre[r] = make_uint4(v.x, v.y, v.z, v.w);
     }
 }
@@ -1164,10 +1164,11 @@ void kvq_probe_text(const uint8_t *text, size_t n, uint32_t &maxline, uint32_t &
     maxline = std::max<uint32_t>(best, (uint32_t)(n - start));
     rec_bytes = lines >= 16 ? (uint32_t)(start * 4 / lines) : 0u;           // (start = bytes in whole lines)
 }
-uint32_t kvq_tile_for_text(const uint8_t *text, size_t n)
+uint32_t kvq_tile_for_text(const uint8_t *text, size_t n, uint32_t *rec_bytes_out)
 {
     uint32_t maxline, rec_bytes;
     kvq_probe_text(text, n, maxline, rec_bytes);
+    if (rec_bytes_out) *rec_bytes_out = rec_bytes;
     return kvq_choose_tile(maxline, rec_bytes);
 }
 

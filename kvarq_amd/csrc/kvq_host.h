@@ -80,6 +80,7 @@ struct kvq_scan {
     // hit arena
     DevBuf d_covdiff;                  // coverage marks (KvqParams::covdiff)
     uint32_t tile_bytes = 0;           // bytes a tile of the seed-filter kernel owns (0 = not chosen yet; kvq_choose_tile)
+    uint32_t rec_bytes = 0;            // average record among the first bytes of the text (0 = unknown)
     DevBuf d_arena, d_blob, d_small;   // d_small: arena_n, batch range words, blob_n, err
     uint32_t arena_cap = 0; uint64_t blob_cap = 0;
     unsigned int *d_arena_n = nullptr, *d_range = nullptr, *d_fail = nullptr, *cur_fail = nullptr;
@@ -119,7 +120,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
 
 uint32_t kvq_choose_tile(uint32_t maxline, uint32_t rec_bytes);
 uint32_t kvq_min_tile();
-uint32_t kvq_tile_for_text(const uint8_t *text, size_t n);
+uint32_t kvq_tile_for_text(const uint8_t *text, size_t n, uint32_t *rec_bytes_out = nullptr);
 
 // synth.hip
 // (C ABI only)

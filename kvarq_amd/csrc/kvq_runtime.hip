@@ -512,7 +512,7 @@ extern "C" int32_t kvq_scan_host_drain(kvq_scan *s)
     const unsigned int fail = *reinterpret_cast<const unsigned int *>(s->pin_small + 40);     // copied behind the batch
     if (!fail) return KVQ_OK;
     s->batches[b].redone = true;
-    s->tile_bytes = kvq_choose_tile(1u << 20, 0);  // (a record may have outgrown the look-ahead: back to the full one)
+    s->tile_bytes = kvq_choose_tile(1u << 20, 0); s->rec_bytes = 0;  // (a record may have outgrown the look-ahead: back to the full one)
     Batch again = s->batches[b]; again.is_redo = true;
     s->batches.push_back(again);
     s->path_bits |= 4;
@@ -533,7 +533,7 @@ extern "C" int32_t kvq_scan_host_async(kvq_scan *s, const void *h_data, int64_t 
     s->pool.used = 0;
     *reinterpret_cast<unsigned int *>(s->pin_small + 40) = 0;    // "speculation failed" of the batch about to be enqueued
     if (s->tile_bytes == 0)                                      // size the seed-filter tiles from the head of the text
-        s->tile_bytes = kvq_tile_for_text((const uint8_t *)h_data, (size_t)std::min<int64_t>(nbytes, 128 << 10));
+        s->tile_bytes = kvq_tile_for_text((const uint8_t *)h_data, (size_t)std::min<int64_t>(nbytes, 128 << 10), &s->rec_bytes);
     if ((rc = s->d_stage.ensure((size_t)nbytes + 64))) return rc;
     if (!s->ev_copied) KVQ_HIP(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
     KVQ_HIP(hipMemcpyAsync(s->d_stage.p, h_data, (size_t)nbytes, hipMemcpyHostToDevice, s->stream));
@@ -594,7 +594,7 @@ static int finish_once(kvq_scan *s)
         for (size_t b = 0; b < nb0; b++) {
             if (!fail[b] || s->batches[b].redone || !s->batches[b].d_data) continue;
             s->batches[b].redone = true;
-            s->tile_bytes = kvq_choose_tile(1u << 20, 0);   // (a record may have outgrown the look-ahead: back to the full one)
+            s->tile_bytes = kvq_choose_tile(1u << 20, 0); s->rec_bytes = 0;   // (a record may have outgrown the look-ahead: back to the full one)
             Batch again = s->batches[b]; again.is_redo = true;
             s->batches.push_back(again);
             s->path_bits |= 4; any = true;
