@@ -50,7 +50,7 @@ struct BpLds {
     uint32_t rinfo[ST_RCAP];             // read offset in the window | rl << 16
     __attribute__((aligned(16))) uint8_t head[BP_HEAD];   // the first bytes of the window as text (P2 looks at line starts there)
     __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];
-    uint32_t longest_p1, records, fallback, n_owned, next_tile;
+    uint32_t longest_p1, records, fallback, n_owned, next_tile, first_tile;
 };
 static_assert(sizeof(BpLds) <= 40 * 1024, "four workgroups per CU: at most 40 KB of LDS each");
 static_assert(offsetof(BpLds, cdp) == 0, "cdp[] first");
@@ -195,6 +195,25 @@ struct BpArgs {
     const uint4 *tiles; uint32_t *tile_report; unsigned int *tile_ctr;
     uint32_t ntiles, tile_bytes, dbg, pad_;
 };
+// Tiles are handed out by counters.  One counter for the whole launch is a ceiling by itself: a word in
+// memory takes about 88 atomic adds per microsecond (MI355X_MICROARCH.md, "dequeue"), i.e. 3.5 TB/s of
+// 40 KB tiles.  So the tiles are dealt into BP_SHARDS contiguous shares with a counter each (on a
+// 128-byte line of its own); a workgroup starts in share blockIdx.x % BP_SHARDS -- workgroups with equal
+// blockIdx.x % 8 tend to sit on one XCD, so a share is streamed through one L2 -- and moves on to the
+// next share when its own has run out.
+#define BP_SHARDS 64u
+#define BP_SHARD_STRIDE 32u          // counters are this many words apart
+__host__ __device__ static inline uint32_t bp_shard_begin(uint32_t sh, uint32_t ntiles) { return (uint32_t)(((uint64_t)sh * ntiles) / BP_SHARDS); }
+// one lane: the next tile of share `sh`, or of the shares behind it; ntiles when there is none left
+__device__ __forceinline__ uint32_t bp_draw(unsigned int *ctr, uint32_t ntiles, uint32_t &sh, uint32_t &left)
+{
+    while (left) {
+        const uint32_t t = atomicAdd(&ctr[sh * BP_SHARD_STRIDE], 1u);
+        if (t < bp_shard_begin(sh + 1u, ntiles)) return t;
+        sh = sh + 1u == BP_SHARDS ? 0u : sh + 1u; left--;
+    }
+    return ntiles;
+}
 typedef const __attribute__((address_space(4))) BpArgs *BpArgsPtr;
 // the block's address, opaque to the compiler from here on: loads through it are issued where they are
 // written, not hoisted to the top of the kernel
@@ -282,7 +301,13 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         ntiles = A->ntiles; tile_bytes = A->tile_bytes; dbg = A->dbg; amin = (uint32_t)A->P.amin;
         const GlbWords bm1 = (GlbWords)A->X.bm1;
         for (int i = tid; i < 2048; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = bm1[i];
-        if (tid == 0) S.next_tile = atomicAdd(A->tile_ctr, 1u);
+    }
+    // the drawing lane (first lane of the last wave, which holds the fewest reads) and its share of the tiles
+    uint32_t my_shard = blockIdx.x % BP_SHARDS, shards_left = BP_SHARDS;
+    if (tid == ST_THREADS - 64) {
+        unsigned int *const ctr = bp_args(A_)->tile_ctr;
+        S.first_tile = bp_draw(ctr, ntiles, my_shard, shards_left);
+        S.next_tile = bp_draw(ctr, ntiles, my_shard, shards_left);
     }
     for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) S.hist[i] = 0;
     if (tid == 0) { S.longest_p1 = 0; S.records = 0; S.fallback = 0; }
@@ -300,17 +325,21 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
 
     const uint32_t addk = (0x80u - amin) * 0x01010101u;
     uint32_t tiles_done = 0;
-    uint32_t gn = rfl(S.next_tile);
-    for (uint32_t g = blockIdx.x; g < ntiles; ) {
+    // The barrier that ends a tile stands at the top of the next one, BEHIND the issue of that tile's loads:
+    // registers are free there, and the wait for the slowest wave hides the way to memory and back.
+    uint32_t g_done = 0xFFFFFFFFu;                                          // the tile this workgroup has just finished
+    for (uint32_t g = rfl(S.first_tile); ; ) {
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
         const uint32_t blk = (uint32_t)tid * ST_BLK;                           // the thread's newline block in the window
         const uint32_t wv = wave * (ST_BLK * 64u / 16u) + (uint32_t)lane;      // the lane's vector of round 0
         if constexpr (STAMPS) stamp_t = __builtin_amdgcn_s_memtime();
         // tile geometry (the per-tile table kvq_expand_tiles wrote: chunk begin, chunk end, tile number)
-        uint32_t Ja, Jb, Jt, g0; GlbBytes text;
+        uint32_t Ja = 0, Jb = 0, Jt = 0, g0 = 0; GlbBytes text = nullptr;
         uint4 pre[ST_ROUNDS];
-        {
+#pragma unroll
+        for (int r = 0; r < (int)ST_ROUNDS; r++) pre[r] = make_uint4(0, 0, 0, 0);      // (no "value of the last tile" for the compiler to keep alive through the whole tile)
+        if (g < ntiles) {
             const BpArgsPtr A = bp_args(A_);
             // (diagnostic 64: every tile scans the text of one of the first 64 tiles -- the same work from L2 instead of HBM; results are wrong)
             const u32x4_t q = ((const __attribute__((address_space(4))) u32x4_t *)A->tiles)[(dbg & 64u) ? (g & 63u) : g];
@@ -330,6 +359,13 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 pre[r] = make_uint4(v.x, v.y, v.z, v.w);
             }
         }
+        // everyone is done with the last tile's planes; its loose ends
+        __syncthreads();
+        if (g_done != 0xFFFFFFFFu) {
+            if (tid == 0 && S.fallback) { atomicOr(&bp_args(A_)->tile_report[g_done], TR_FLAG_FALLBACK); S.fallback = 0; }
+        }
+        if (g >= ntiles) break;
+        const uint32_t gn = rfl(S.next_tile);
         const uint32_t own_end = g0 + tile_bytes < Jb ? g0 + tile_bytes : Jb;
         const uint32_t load_hi = g0 + ST_TILE + ST_OV < Jb ? g0 + ST_TILE + ST_OV : Jb;
         const uint32_t own_begin_l = (Jt == 0 ? Ja : g0) - g0 + ST_PRE;       // window offsets: first owned byte,
@@ -458,10 +494,21 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 if (tid == 0) {
                     A->tile_report[g] = (n_owned & 0xFFFFu) | ((jn & 0xFFu) << 16) | (fallback ? TR_FLAG_FALLBACK : 0u);
                     S.records += nrec;
-                } else drawn = atomicAdd(A->tile_ctr, 1u);
+                } else if (shards_left) drawn = atomicAdd(&A->tile_ctr[my_shard * BP_SHARD_STRIDE], 1u);
             }
         }
 
+        // now and then the read-length histogram goes to the global counters (16-bit bins); waves that are
+        // already counting this tile's reads may add to a bin at any time: it is taken and cleared in one step
+        if (++tiles_done == ST_HIST_TILES) {
+            unsigned long long *const ctr = bp_args(A_)->P.ctr;
+            for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) {
+                const uint32_t w = atomicExch(&S.hist[i], 0u);
+                if (w & 0xFFFFu) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i], (unsigned long long)(w & 0xFFFFu));
+                if (w >> 16) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i + 1], (unsigned long long)(w >> 16));
+            }
+            tiles_done = 0;
+        }
         if (dbg & 32u) nrec = 0;                                     // diagnostic: front end only
         KVQ_MARK("P2 end / P3 setup");
         BSTAMP(3);
@@ -726,22 +773,18 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         }
         if constexpr (STAMPS) wave_p34 += __builtin_amdgcn_s_memtime() - wave_t3;
         // everyone is done with the tile's planes before the next tile's fill
-        if (tid == ST_THREADS - 64) S.next_tile = drawn;
-        __syncthreads();
+        if (tid == ST_THREADS - 64) {
+            // (the share has run out: on to the next one, now and here -- this happens BP_SHARDS times per workgroup at most)
+            if (!shards_left) drawn = ntiles;
+            else if (drawn >= bp_shard_begin(my_shard + 1u, ntiles)) {
+                my_shard = my_shard + 1u == BP_SHARDS ? 0u : my_shard + 1u; shards_left--;
+                drawn = bp_draw(bp_args(A_)->tile_ctr, ntiles, my_shard, shards_left);
+            }
+            S.next_tile = drawn;
+        }
         KVQ_MARK("tile end");
         BSTAMP(7);
-        if (tid == 0 && S.fallback) { atomicOr(&bp_args(A_)->tile_report[g], TR_FLAG_FALLBACK); S.fallback = 0; }
-        g = gn; gn = rfl(S.next_tile);
-        if (++tiles_done == ST_HIST_TILES) {
-            unsigned long long *const ctr = bp_args(A_)->P.ctr;
-            for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) {
-                const uint32_t w = S.hist[i];
-                if (w & 0xFFFFu) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i], (unsigned long long)(w & 0xFFFFu));
-                if (w >> 16) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i + 1], (unsigned long long)(w >> 16));
-                S.hist[i] = 0;
-            }
-            tiles_done = 0;      // (the next updates of the histogram lie behind the next tile's barriers)
-        }
+        g_done = g; g = gn;
     }
 
     unsigned long long *const ctr = bp_args(A_)->P.ctr;
@@ -790,12 +833,13 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     // workgroups per launch: what the CUs hold at once (kvq_scan_bp four per CU, kvq_scan_seeded two)
     static const uint32_t grid_env = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 0);
     const uint32_t grid_cap = grid_env ? grid_env : ix->variant ? 512u : 1024u;
-    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 8192 > s->pool.cap) {       // run_batch made the room
+    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 24576 > s->pool.cap) {       // run_batch made the room
         kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;
     }
     // first tile of every chunk, then the parameter block: one copy
     const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
-    const size_t first_at = s->pool.take(first_b + sizeof(BpArgs) + 16);         // ... and the tile counter behind it
+    const size_t ctr_b = 256 + 4 * BP_SHARDS * BP_SHARD_STRIDE;                  // the tile counters (kvq_scan_seeded: one; kvq_scan_bp: BP_SHARDS)
+    const size_t first_at = s->pool.take(first_b + sizeof(BpArgs) + ctr_b);      // ... and the tile counters behind it
     const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 4);
     uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
     uint64_t acc = 0;
@@ -812,7 +856,8 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     const KvqParams *d_params = &d_args->P;
     uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
     uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
-    unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + first_at + first_b + sizeof(BpArgs));
+    const size_t ctr_at = first_at + first_b + ((sizeof(BpArgs) + 127) & ~(size_t)127);
+    unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + ctr_at);
     {
         // the argument block of the scan kernel (kvq_scan_seeded reads its first member, the parameters)
         BpArgs a;
@@ -822,9 +867,14 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         a.ntiles = (uint32_t)nt; a.tile_bytes = TILE; a.dbg = dbg;
         memcpy(s->pool.h + first_at + first_b, &a, sizeof(a));
     }
-    memcpy(s->pool.h + first_at + first_b + sizeof(BpArgs), &grid_seeded, 4);              // tiles below this number are the workgroups' first
-    // chunk offsets (run_batch put them right in front), first tiles, arguments, tile counter: one transfer
-    KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, first_at + first_b + sizeof(BpArgs) + 16 - s->cur_co_at,
+    {
+        unsigned int *hc = reinterpret_cast<unsigned int *>(s->pool.h + ctr_at);
+        memset(hc, 0, 4 * BP_SHARDS * BP_SHARD_STRIDE);
+        if (ix->variant) hc[0] = grid_seeded;                                              // kvq_scan_seeded: tiles below this number are the workgroups' first
+        else for (uint32_t sh = 0; sh < BP_SHARDS; sh++) hc[sh * BP_SHARD_STRIDE] = bp_shard_begin(sh, (uint32_t)nt);
+    }
+    // chunk offsets (run_batch put them right in front), first tiles, arguments, tile counters: one transfer
+    KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, ctr_at + 4 * BP_SHARDS * BP_SHARD_STRIDE - s->cur_co_at,
                            hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
 

@@ -385,7 +385,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     // block, tile table and tile reports in kvq_seeded_launch, whose tiles own at least kvq_min_tile() bytes --
     // is made in one go: the pool must not move between the two)
     const size_t tiles_bound = (size_t)(nbytes / kvq_min_tile()) + (size_t)nchunks + 2;
-    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 8 + tiles_bound * 20 + 16384, s->stream))) return rc;
+    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 8 + tiles_bound * 20 + 32768, s->stream))) return rc;
     const size_t co_at = s->pool.take(((size_t)nchunks + 1) * 4);
     s->cur_co_at = co_at;
     uint32_t *co = reinterpret_cast<uint32_t *>(s->pool.h + co_at);
