@@ -28,6 +28,7 @@
 #define BP_QW 96                   // candidates per wave and stretch
 #define BP_Q2W 96                  // work items per wave and stretch
 #define BP_NLCAP 1920              // newlines per window (beyond: the tile raises its fallback flag)
+#define BP_P2_LATE 0xFFFEu          // "wave 0 could not tell the tile's first record"
 #define BP_HEAD 2048u              // bytes of raw text kept for P2
 #define BP_QCAP (BP_QW * ST_WAVES)
 #define BP_Q2CAP (BP_Q2W * ST_WAVES)
@@ -50,7 +51,7 @@ struct BpLds {
     uint32_t rinfo[ST_RCAP];             // read offset in the window | rl << 16
     __attribute__((aligned(16))) uint8_t head[BP_HEAD];   // the first bytes of the window as text (P2 looks at line starts there)
     __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];
-    uint32_t longest_p1, records, fallback, n_owned, next_tile, first_tile;
+    uint32_t longest_p1, records, fallback, n_owned, next_tile, first_tile, p2_jn;
 };
 static_assert(sizeof(BpLds) <= 40 * 1024, "four workgroups per CU: at most 40 KB of LDS each");
 static_assert(offsetof(BpLds, cdp) == 0, "cdp[] first");
@@ -373,7 +374,6 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         const uint32_t end_l = load_hi - g0 + ST_PRE;                         // end of the loaded text
 
         // ---- P0: registers -> planes; the thread's 80 newline flags ----
-        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0)
         // bytes in front of the chunk's first byte (when that is not 16-byte aligned) and behind its last
         // one are zeroed in place by the wave whose stretch holds them (rare: scalar test)
         {
@@ -451,18 +451,45 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 }
             }
         }
+        // Which record is the tile's first?  Speculated from the text: an '@' line followed two lines later by
+        // a '+' line, among the first eight lines (P2 below turns it into the records the tile owns, and
+        // kvq_validate_tiles checks it against the exact newline count after the kernel).  The ten newlines
+        // this looks at nearly always lie in wave 0's stretch, whose entries of the list are its own: it works
+        // the answer out here, once, and the other seven waves read it behind the barrier.
+        if (wave == 0u) {
+            const uint32_t cnt0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t early = BP_P2_LATE;
+            if (Jt != 0 && cnt0 >= 10u) {
+                const uint32_t m = (uint32_t)lane;
+                bool ok = false;
+                if (m >= 1 && m <= 8) {
+                    const uint32_t e0 = S.nl[m - 1], e2 = S.nl[m + 1];
+                    const uint32_t ls0 = e0 + 1u, ls2 = e2 + 1u;
+                    if (e0 < own_end_l && ls0 < end_l && ls2 < end_l) {
+                        const uint32_t c0 = ls0 < BP_HEAD ? lds_byte_at(BP_LDS_HEAD + ls0) : (uint32_t)text[ls0];
+                        const uint32_t c2 = ls2 < BP_HEAD ? lds_byte_at(BP_LDS_HEAD + ls2) : (uint32_t)text[ls2];
+                        ok = c0 == '@' && c2 == '+';
+                    }
+                }
+                const uint64_t mk = __ballot(ok);
+                early = mk ? (uint32_t)(__ffsll((long long)mk) - 1) : TR_NONE;
+            }
+            if (lane == 0) S.p2_jn = early;
+        }
         __syncthreads();
         KVQ_MARK("P1b end / P2");
         BSTAMP(2);
 
         // ---- P2 (every wave, redundantly): which records does this tile own? ----
-        uint32_t nrec = 0, jn = TR_NONE, drawn = 0;
+        uint32_t nrec = 0, jn = TR_NONE, drawn;                     // (drawn: the drawing lane's only)
         {
             const uint32_t n_nl = n_all < BP_NLCAP ? n_all : BP_NLCAP;
             const uint32_t n_owned = rfl(S.n_owned);
             uint32_t fallback = n_all > BP_NLCAP ? 1u : 0u;
             if (Jt == 0) jn = 0;                                            // chunk start: exact
+            else if (const uint32_t early = rfl(S.p2_jn); early != BP_P2_LATE) jn = early;      // wave 0 has seen it already (below)
             else {
+                // (the general form: the tile's first ten newlines did not all lie in wave 0's stretch)
                 const uint32_t m = (uint32_t)lane;
                 bool ok = false;
                 if (m >= 1 && m <= 8 && m <= n_owned && m + 2 <= n_nl) {
@@ -530,7 +557,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
             const uint32_t k = pass0 + gr;
             const bool have = k < nrec;
             uint32_t roff = 0; int rl = 0;
-            uint32_t c0 = '@', cp = '+';                            // the record's '@' and '+' (1037-1048): fetched here, looked at behind the pass
+            uint32_t c0, cp;                                        // the record's '@' and '+' (1037-1048): fetched here by the group's first lane, looked at behind the pass
             if (have) {
                 const uint32_t m = jn + 4u * k;
                 const uint32_t rstart = m == 0 ? ST_PRE + (Ja & 15u) : (uint32_t)S.nl[m - 1] + 1u;
@@ -627,15 +654,18 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                     e1 = e0 + per; if (e1 > NPe) e1 = NPe;
                 }
                 // is the 8-mer at read position pp anywhere in a sequence?  (bitmap of all sequence 8-mers: global memory)
+                // (the load is issued whether the block is wanted or not -- any code has its byte in the bitmap --
+                // so that the two lookups of a lane travel together instead of each behind a branch of its own)
                 auto fixed_block = [&](int pp, bool ok) -> bool {
                     const uint32_t code = cdp_code8(roff + (uint32_t)(ok ? pp : 0));
-                    return ok && ((bmL[code >> 3] >> (code & 7u)) & 1u);
+                    const uint32_t bits = bmL[code >> 3];
+                    return ok & (bool)((bits >> (code & 7u)) & 1u);
                 };
                 auto head_ok = [&](int jj) { return mine && jj <= me_ && (jj + 1) * SK <= rl; };
                 auto tail_ok = [&](int jj) { const int pp = rl - (jj + 1) * SK; return mine && jj <= me_ && pp >= 0 && !((pp % SK) == 0 && pp <= me_ * SK); };
                 const bool hhit = fixed_block((int)gl * SK, head_ok((int)gl));
                 const bool thit = fixed_block(rl - ((int)gl + 1) * SK, tail_ok((int)gl));
-                constexpr int NR = SS == 8 ? 6 : 48 / SS;                        // lookups per lane and round
+                constexpr int NR = SS == 8 ? 6 : SS == 4 ? 12 : 18;              // lookups per lane and round (18: a 150-base read's 72 even positions over four lanes)
                 bool first = true;
                 for (int ee = e0; __any(ee < e1); ee += NR, first = false) {
                     const bool act = ee < e1;
@@ -651,7 +681,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                         uint32_t R[NW - 1];
 #pragma unroll
                         for (int t = 0; t < NW - 1; t++) R[t] = __builtin_amdgcn_alignbit(W[t + 1], W[t], bo);
-                        constexpr int NB = SS == 8 ? 6 : 8;
+                        constexpr int NB = 6;
 #pragma unroll
                         for (int j0 = 0; j0 < NR; j0 += NB) {
                             uint32_t bi[NB], bb[NB];
@@ -760,7 +790,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
             }
             KVQ_SETPRIO(0);
             // the '@' / '+' checks of the pass's records (the bytes have come back long ago)
-            if (have && gl == 0 && (c0 != '@' || cp != '+')) {
+            if (have && gl == 0 && (c0 != '@' || cp != '+')) {          // (lanes that fetched nothing never look)
                 const BpArgsPtr A = bp_args(A_);
                 const uint32_t m = jn + 4u * k;
                 const uint32_t rstart = m == 0 ? ST_PRE + (Ja & 15u) : (uint32_t)S.nl[m - 1] + 1u, plus = (uint32_t)S.nl[m + 1] + 1u;
