@@ -329,6 +329,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     // The barrier that ends a tile stands at the top of the next one, BEHIND the issue of that tile's loads:
     // registers are free there, and the wait for the slowest wave hides the way to memory and back.
     uint32_t g_done = 0xFFFFFFFFu;                                          // the tile this workgroup has just finished
+    uint32_t my_longest = 0;                                                // 1 + the longest read this lane has trimmed
     for (uint32_t g = rfl(S.first_tile); ; ) {
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
@@ -622,9 +623,11 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                     rl = __shfl(sg.best, lane & ~(int)(G - 1u), 64);
                     roff = sread + (uint32_t)__shfl(sg.bstart, lane & ~(int)(G - 1u), 64);             // 1070
                 }
+                // (the longest read: a running maximum per lane, put together once at the end of the kernel -- an
+                // atomic maximum in LDS per read is turned into a scalar loop over the wave's lanes by the compiler)
+                my_longest = my_longest > (uint32_t)(rl + 1) ? my_longest : (uint32_t)(rl + 1);
                 if (gl == 0) {
                     if (rl < KVQ_RL_BINS) atomicAdd(&S.hist[rl >> 1], 1u << (16 * (rl & 1)));          // 394-402
-                    atomicMax(&S.longest_p1, (uint32_t)(rl + 1));
                     S.rinfo[k] = roff | ((uint32_t)rl << 16);
                 }
             }
@@ -817,6 +820,8 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         g_done = g; g = gn;
     }
 
+    atomicMax(&S.longest_p1, my_longest);
+    __syncthreads();
     unsigned long long *const ctr = bp_args(A_)->P.ctr;
     if constexpr (STAMPS) {
         if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
