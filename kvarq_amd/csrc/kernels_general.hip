@@ -9,7 +9,7 @@
 //   kvq_index_records  positions of the four '\n' of every complete record     (1024-1029)
 //   kvq_trim_records   '@'/'+' checks, longest quality run, length histogram   (1037-1070)
 //   kvq_match_all      every read against every listed sequence, classes A/B/C (1107-1175)
-//   kvq_fold_hits      per-sequence counters, coverage/mutation fold, hit bytes (434-439, analyse.py:57-78)
+//   kvq_fold_batch     per-sequence counters, coverage/mutation fold, hit bytes (434-439, analyse.py:57-78)
 #include "kvq_device.h"
 
 // ---------------------------------------------------------------------------
@@ -297,11 +297,15 @@ __device__ __forceinline__ int base_class(uint8_t c)
     return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : 5;
 }
 
-// hits [*range_begin, min(*range_end, cap)) of the arena, first pass, one LANE per hit: per-hit
-// counters, coverage marks, and the place of the hit's bytes in the blob (prefix sum over the
-// wave's 64 hits, one reservation per wave -- a reservation per hit would queue up on blob_n).
+// The fold of one batch's hits [*range_begin, min(*range_end, cap)) of the arena, a LANE per hit: per-sequence
+// counters, coverage marks, the place of the hit's bytes in the blob (prefix sum over the wave's 64 hits, one
+// reservation per wave -- a reservation per hit would queue up on blob_n), then the hit's bases one by one:
+// hit bytes into the blob, mutation counters (analyse.py:57-78).  (Hits are a few dozen bytes: 64 of them side
+// by side keep 64 independent byte streams in flight, where a wave per hit waits out the way to memory and
+// back once per hit.)
 extern "C" __global__ void __launch_bounds__(256)
-kvq_fold_offsets(KvqParams P, const unsigned int *__restrict__ range_begin, const unsigned int *__restrict__ range_end)
+kvq_fold_batch(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base,
+               const unsigned int *__restrict__ range_begin, const unsigned int *__restrict__ range_end)
 {
     const uint32_t h0 = *range_begin;
     uint32_t h1 = *range_end; if (h1 > P.arena_cap) h1 = P.arena_cap;
@@ -311,12 +315,12 @@ kvq_fold_offsets(KvqParams P, const unsigned int *__restrict__ range_begin, cons
     for (uint32_t hb = h0 + wave * 64u; hb < h1; hb += nwaves * 64u) {
         const uint32_t h = hb + (uint32_t)lane;
         const bool valid = h < h1;
-        int s = 0, len = 0, seq_pos = 0;
-        if (valid) { const KvqHit hit = P.arena[h]; s = hit.seq_nr; len = hit.length; seq_pos = hit.seq_pos; }
+        int s = 0, len = 0, seq_pos = 0; int64_t fpos = 0;
+        if (valid) { const KvqHit hit = P.arena[h]; s = hit.seq_nr; len = hit.length; seq_pos = hit.seq_pos; fpos = hit.fpos; }
         const uint32_t ulen = len > 0 ? (uint32_t)len : 0u;
+        const int start = seq_pos > 0 ? seq_pos : 0;                                  // analyse.py:70
+        const int64_t at = (int64_t)(valid ? P.tab_off[s] : 0) + start;
         if (valid) {
-            const int start = seq_pos > 0 ? seq_pos : 0;                              // analyse.py:70
-            const int64_t at = (int64_t)P.tab_off[s] + start;
             atomicAdd(&P.ctr[P.off_nseqhits + s], 1ull);                              // 435
             atomicAdd(&P.ctr[P.off_nseqbasehits + s], (unsigned long long)len);       // 434
             if (len > 0) {
@@ -331,37 +335,33 @@ kvq_fold_offsets(KvqParams P, const unsigned int *__restrict__ range_begin, cons
         if (lane == 0 && tot) base = atomicAdd(P.blob_n, (unsigned long long)tot);
         base = ((unsigned long long)__shfl((unsigned int)(base >> 32), 0, 64) << 32) | __shfl((unsigned int)base, 0, 64);
         const unsigned long long boff = base + incl - ulen;
-        if (valid) P.arena[h].blob_off = boff + ulen <= P.blob_cap ? (uint32_t)boff : 0xFFFFFFFFu;
-    }
-}
-
-// second pass, one WAVE per hit: the lanes share out the hit's bases (hit bytes into the blob at
-// the offset the first pass chose, mutation counters)
-extern "C" __global__ void __launch_bounds__(256)
-kvq_fold_hits(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base,
-              const unsigned int *__restrict__ range_begin, const unsigned int *__restrict__ range_end)
-{
-    const uint32_t h0 = *range_begin;
-    uint32_t h1 = *range_end; if (h1 > P.arena_cap) h1 = P.arena_cap;
-    const int lane = kvq_lane();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t h = h0 + wave; h < h1; h += nwaves) {
-        const KvqHit hit = P.arena[h];
-        const int s = hit.seq_nr, len = hit.length;
-        const int start = hit.seq_pos > 0 ? hit.seq_pos : 0;                          // analyse.py:70
-        const uint8_t *src = data + (hit.fpos - fpos_base) + (hit.seq_pos < 0 ? -hit.seq_pos : 0);
-        const uint8_t *seq = P.tab + P.tab_off[s] + start;
-        const int64_t at = (int64_t)P.tab_off[s] + start;
-        const bool fits = hit.blob_off != 0xFFFFFFFFu;
-        for (int j = lane; j < len; j += 64) {
-            const uint8_t c = src[j];
-            if (c != seq[j]) atomicAdd(&P.ctr[P.off_mut + (at + j) * 6 + base_class(c)], 1ull);   // analyse.py:77-78
-            if (fits) P.blob[(size_t)hit.blob_off + j] = c;                           // 437
+        const bool fits = boff + ulen <= P.blob_cap;
+        if (valid) P.arena[h].blob_off = fits ? (uint32_t)boff : 0xFFFFFFFFu;
+        const uint8_t *src = data + (fpos - fpos_base) + (seq_pos < 0 ? -seq_pos : 0);
+        const uint8_t *seq = P.tab + at;
+        uint8_t *dst = P.blob + boff;
+        // four bases a step (unaligned dwords; the buffers have slack behind their ends), all loads of a step in flight together
+        for (uint32_t q = 0; __any(q < ulen); q += 4u) {
+            if (q < ulen) {
+                uint32_t x, y;
+                __builtin_memcpy(&x, src + q, 4); __builtin_memcpy(&y, seq + q, 4);
+                const uint32_t nq = ulen - q < 4u ? ulen - q : 4u;
+                if (nq < 4u) { const uint32_t keep = (1u << (8u * nq)) - 1u; y = (y & keep) | (x & ~keep); }      // (bytes behind the hit: "equal")
+                if (x != y)
+                    for (uint32_t j = 0; j < nq; j++) {
+                        const uint8_t c = (uint8_t)(x >> (8u * j));
+                        if (c != (uint8_t)(y >> (8u * j))) atomicAdd(&P.ctr[P.off_mut + (at + q + j) * 6 + base_class(c)], 1ull);   // analyse.py:77-78
+                    }
+                if (fits) {                                                           // 437
+                    if (nq == 4u) __builtin_memcpy(dst + q, &x, 4);
+                    else for (uint32_t j = 0; j < nq; j++) dst[q + j] = (uint8_t)(x >> (8u * j));
+                }
+            }
         }
     }
 }
 
-// one wave per sequence: running sum of the coverage marks kvq_fold_hits left, added to the
+// one wave per sequence: running sum of the coverage marks kvq_fold_batch left, added to the
 // coverage counters; the marks are cleared on the way
 extern "C" __global__ void __launch_bounds__(256)
 kvq_cov_apply(KvqParams P)

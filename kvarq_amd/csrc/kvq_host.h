@@ -102,7 +102,10 @@ struct kvq_scan {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_all, ev_main, ev_free;     // ev_free: pairs of earlier scans, reused
     double ms_all = 0, ms_main = 0; int64_t main_launches = 0;
     // results: ordered and laid out on the device (kernels_results.hip), one copy into pinned host memory
-    DevBuf d_sort_tmp, d_sorted, d_result;
+    DevBuf d_sort_tmp, d_sorted, d_result, d_order, d_finish;   // d_order: bucket arrays of the ordering; d_finish: KvqFinishState
+    uint32_t order_nb_max = 0;                    // the bucket arrays in d_order are laid out for this many buckets
+    uint8_t *pin_res = nullptr;                   // where the result arrays start inside pin (behind the counters)
+    size_t spec_bytes = 1u << 20;                 // result bytes fetched together with the counters, before their number is known (the last scan's)
     uint8_t *pin = nullptr; size_t pin_cap = 0;   // pinned landing buffer of finish: the result arrays, then the counters
     uint8_t *pin_small = nullptr;                 // pinned landing buffer for the scan's small words and fail flags
     KvqResultLayout res;                          // where the arrays sit inside pin

@@ -221,13 +221,16 @@ kvq_reset_state(unsigned long long *small, size_t small_words, unsigned long lon
     for (size_t i = i0; i < cov_words; i += step) cov[i] = 0ull;
 }
 
-// the scan's eight small words and its per-batch "speculation failed" flags -> pinned host memory
+// the scan's eight small words, its per-batch "speculation failed" flags and what kvq_finish_plan and the
+// ordering left (hit count, layout, "crowded") -> pinned host memory
 extern "C" __global__ void __launch_bounds__(256)
 kvq_publish_small(const unsigned int *__restrict__ small, const unsigned int *__restrict__ fail, unsigned int nbatches,
-                  unsigned int *host_small, unsigned int *host_fail)
+                  const unsigned int *__restrict__ state, unsigned int state_words,
+                  unsigned int *host_small, unsigned int *host_fail, unsigned int *host_state)
 {
     if (threadIdx.x < 8) host_small[threadIdx.x] = small[threadIdx.x];
     for (unsigned int i = threadIdx.x; i < nbatches; i += blockDim.x) host_fail[i] = fail[i];
+    for (unsigned int i = threadIdx.x; i < state_words; i += blockDim.x) host_state[i] = state[i];
     __threadfence_system();
 }
 
@@ -279,12 +282,13 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     s->d_stage_ctr = (unsigned long long *)((char *)s->d_small.p + SMALL_STAGE);
     if (ensure_arena(s, 1u << 20, 64ull << 20) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     s->pin_cap = (size_t)t->ctr_len * 8 + (4u << 20);
-    if (hipHostMalloc((void **)&s->pin_small, 64 + 4 * (size_t)KVQ_MAX_BATCHES, hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void **)&s->pin_small, 64 + 4 * (size_t)KVQ_MAX_BATCHES + 512, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&s->pin, s->pin_cap, hipHostMallocDefault) != hipSuccess) {
         kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); kvq_scan_destroy(s); return nullptr;
     }
-    memset(s->pin, 0, 4096);
+    memset(s->pin, 0, s->pin_cap < (1u << 20) ? s->pin_cap : (1u << 20));
     s->res = kvq_result_layout(0, 0);
+    s->pin_res = s->pin + ((((size_t)t->ctr_len * 8) + 255) & ~(size_t)255);
     if (reset_device_state(s) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     s->h_ctr.assign((size_t)t->ctr_len, 0);
     return s;
@@ -309,7 +313,7 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     if (s->pin) (void)hipHostFree(s->pin);
     if (s->pin_small) (void)hipHostFree(s->pin_small);
     if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
-    DevBuf *bufs[] = { &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_covdiff, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
+    DevBuf *bufs[] = { &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_order, &s->d_finish, &s->d_covdiff, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
                        &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
     for (DevBuf *b : bufs) b->release();
     s->pool.release();
@@ -478,9 +482,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
                            (const unsigned int *)(s->d_fail + batch_no), s->d_arena_n, s->d_range + batch_no);
     else
         KVQ_HIP(hipMemcpyAsync(s->d_range + batch_no + 1, s->d_arena_n, 4, hipMemcpyDeviceToDevice, s->stream));
-    hipLaunchKernelGGL(kvq_fold_offsets, dim3(64), dim3(256), 0, s->stream, P,
-                       (const unsigned int *)(s->d_range + batch_no), (const unsigned int *)(s->d_range + batch_no + 1));
-    hipLaunchKernelGGL(kvq_fold_hits, dim3(512), dim3(256), 0, s->stream, P, d_data, fpos_base,
+    hipLaunchKernelGGL(kvq_fold_batch, dim3(512), dim3(256), 0, s->stream, P, d_data, fpos_base,
                        (const unsigned int *)(s->d_range + batch_no), (const unsigned int *)(s->d_range + batch_no + 1));
     KVQ_HIP(hipEventRecord(s->ev_all.back().second, s->stream));
     KVQ_HIP(hipGetLastError());
@@ -569,105 +571,129 @@ static int finish_once(kvq_scan *s)
 {
     const double t0 = now_ms();
     { const int rc0 = kvq_scan_host_drain(s); if (rc0) return rc0; }          // settle the host batch in flight
-    // the scan's small words (hit count, hit bytes, first error) and the per-batch "speculation
-    // failed" flags arrive behind everything that is enqueued: one wait for all of it
-    const size_t nb0 = s->batches.size();
-    unsigned char *small = s->pin_small; unsigned int *fail = reinterpret_cast<unsigned int *>(s->pin_small + 64);
-    auto fetch_small = [&]() -> int {
-        // one small kernel stores the words straight into the pinned host buffer (two copy
-        // engine transfers would each cost a launch)
-        hipLaunchKernelGGL(kvq_publish_small, dim3(1), dim3(256), 0, s->stream, (const unsigned int *)s->d_small.p,
-                           (const unsigned int *)s->d_fail, (unsigned int)s->batches.size(), (unsigned int *)small, fail);
-        KVQ_HIP(hipGetLastError());
-        KVQ_HIP(hipStreamSynchronize(s->stream));
-        return KVQ_OK;
-    };
     int rc;
-    if ((rc = fetch_small())) return rc;
-    const double t1 = now_ms();
-    // batches whose seed-filter pass failed validation (a tile's speculated record split
-    // disagreed with the newline count, or a record outgrew the tile look-ahead) were rolled
-    // back on the device: scan those again with the exhaustive kernels (device batches only;
-    // host batches were redone on the spot)
-    if (nb0 && (s->path_bits & 1)) {
-        bool any = false;
-        for (size_t b = 0; b < nb0; b++) {
-            if (!fail[b] || s->batches[b].redone || !s->batches[b].d_data) continue;
-            s->batches[b].redone = true;
-            s->tile_bytes = kvq_choose_tile(1u << 20, 0); s->rec_bytes = 0;   // (a record may have outgrown the look-ahead: back to the full one)
-            Batch again = s->batches[b]; again.is_redo = true;
-            s->batches.push_back(again);
-            s->path_bits |= 4; any = true;
-            rc = run_batch(s, again.d_data, again.nbytes, again.chunk_off.data(), (int64_t)again.chunk_off.size() - 1,
-                           again.fpos_base, s->batches.size() - 1, true);
-            if (rc) return rc;
-        }
-        if (any && (rc = fetch_small())) return rc;
-    }
-    unsigned int n_hits; unsigned long long blob_n, err;
-    memcpy(&n_hits, small, 4); memcpy(&blob_n, small + 8, 8); memcpy(&err, small + 16, 8);
-    if (err != ~0ull) {
-        // first malformed record in stream order (workhorse.c:1037-1048)
-        const long fpos = (long)(err >> 16); const int kind = (int)((err >> 8) & 0xFF); const int ch = (int)(err & 0xFF);
-        if (kind == 0) kvq_set_error(KVQ_ERR_FORMAT, "record must start with '@' (and not '%c') fpos=%ld", ch, fpos);
-        else kvq_set_error(KVQ_ERR_FORMAT, "3rd line of record must start with '+' fpos=%ld", fpos);
-        return KVQ_ERR_FORMAT;
-    }
-    if (n_hits > s->arena_cap || blob_n > s->blob_cap) {
-        // grow to what this scan needs and ask for a rescan
-        const uint64_t want_hits = std::max<uint64_t>(n_hits + n_hits / 8 + 1024, s->arena_cap);
-        // blob_n undercounts when the arena overflowed (dropped hits were never folded): scale it
-        uint64_t want_blob = blob_n;
-        if (n_hits > s->arena_cap && s->arena_cap) want_blob = (uint64_t)((double)blob_n * ((double)n_hits / s->arena_cap) * 1.25) + (1 << 20);
-        want_blob = std::max<uint64_t>(want_blob + want_blob / 8, s->blob_cap);
-        rc = ensure_arena(s, want_hits, want_blob); if (rc) return rc;
-        return KVQ_NEED_RESCAN;
-    }
-    // coverage marks of all batches -> coverage counters
-    if (s->t->nseq > 0)
-        hipLaunchKernelGGL(kvq_cov_apply, dim3((uint32_t)((s->t->nseq + 3) / 4)), dim3(256), 0, s->stream, make_params(s));
-    // results: put into canonical order and into their final arrays on the device
-    // (kernels_results.hip), then one pinned host buffer takes the arrays and the counters
-    const KvqResultLayout L = kvq_result_layout(n_hits, blob_n);
-    const size_t ctr_b = (size_t)s->t->ctr_len * 8;
-    if (L.total + ctr_b > s->pin_cap) {
-        if (s->pin) (void)hipHostFree(s->pin);
-        s->pin = nullptr; s->pin_cap = 0;
-        const size_t want = (L.total + ctr_b) * 5 / 4 + (1 << 20);
-        if (hipHostMalloc((void **)&s->pin, want, hipHostMallocDefault) != hipSuccess) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); return KVQ_ERR_MEMORY; }
-        s->pin_cap = want;
-    }
-    if ((rc = s->d_result.ensure(L.total + 256))) return rc;
-    // file positions of this scan lie in [lo, hi)
-    int64_t lo = 0, hi = 1;
-    for (size_t b = 0; b < s->batches.size(); b++) {
-        const int64_t a = s->batches[b].fpos_base, e = a + s->batches[b].nbytes;
-        if (b == 0 || a < lo) lo = a;
-        if (b == 0 || e > hi) hi = e;
-    }
+    const kvq_table *t = s->t;
+    const size_t ctr_b = ((size_t)t->ctr_len * 8 + 255) & ~(size_t)255;
+    unsigned char *small = s->pin_small; unsigned int *fail = reinterpret_cast<unsigned int *>(s->pin_small + 64);
+    const KvqFinishState *h_st = reinterpret_cast<const KvqFinishState *>(s->pin_small + 64 + 4 * (size_t)KVQ_MAX_BATCHES);
     static const bool no_buckets = getenv("KVQ_ORDER") && !strcmp(getenv("KVQ_ORDER"), "mergesort");
-    unsigned int *d_crowded = reinterpret_cast<unsigned int *>((char *)s->d_small.p + 32);
-    unsigned int *h_crowded = reinterpret_cast<unsigned int *>(s->pin_small + 32);
-    *h_crowded = 0;
-    for (int attempt = no_buckets ? 1 : 0; attempt < 2; attempt++) {
-        if ((rc = kvq_order_results(s->stream, s->d_arena.as<KvqHit>(), n_hits, s->d_blob.as<uint8_t>(), s->d_sort_tmp, s->d_sorted,
-                                    s->d_result.as<uint8_t>(), L, attempt == 0, lo, hi, d_crowded))) return rc;
-        if (n_hits) KVQ_HIP(hipMemcpyAsync(s->pin, s->d_result.p, L.total, hipMemcpyDeviceToHost, s->stream));
-        if (n_hits && attempt == 0) KVQ_HIP(hipMemcpyAsync(h_crowded, d_crowded, 4, hipMemcpyDeviceToHost, s->stream));
-        KVQ_HIP(hipMemcpyAsync(s->pin + L.total, s->d_ctr, ctr_b, hipMemcpyDeviceToHost, s->stream));
-        KVQ_HIP(hipStreamSynchronize(s->stream));
-        if (attempt == 1 || !n_hits || !*h_crowded) break;       // (crowded buckets: once more, with the comparison sort)
-    }
-    memcpy(s->h_ctr.data(), s->pin + L.total, ctr_b);
-    if (!n_hits) memset(s->pin + L.hitseq_off, 0, 8);
-    s->res = L; s->n_hits = n_hits;
 
-    s->ms_all = s->ms_main = 0;
-    for (auto &e : s->ev_all) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_all += ms; }
-    for (auto &e : s->ev_main) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_main += ms; }
-    s->finished = true;
-    if (g_timing) fprintf(stderr, "finish: wait %.3f  order + d2h %.3f ms (%u hits)\n", t1 - t0, now_ms() - t1, n_hits);
-    return KVQ_OK;
+    for (int round = 0; round < 3; round++) {
+        // The whole tail is enqueued behind the scan's kernels -- coverage marks -> counters, the plan of the
+        // ordering, the ordering itself, the gather into the result arrays, the words the host needs, the copies
+        // -- and waited for ONCE: nothing in it needs a number the host would first have to fetch.
+        uint32_t nb_max = 256; while ((uint64_t)nb_max < 4ull * s->arena_cap && nb_max < KVQ_BUCKETS_MAX) nb_max <<= 1;
+        const size_t order_b = kvq_order_scratch_zero_bytes(nb_max) + (size_t)s->arena_cap * 4;
+        if (order_b > s->d_order.cap || nb_max != s->order_nb_max) {
+            if ((rc = s->d_order.ensure(order_b))) return rc;
+            KVQ_HIP(hipMemsetAsync(s->d_order.p, 0, kvq_order_scratch_zero_bytes(nb_max), s->stream));    // (kvq_order_clear leaves them zero again)
+            s->order_nb_max = nb_max;
+        }
+        const KvqOrderScratch W = kvq_order_scratch(s->d_order.p, nb_max);
+        if ((rc = s->d_finish.ensure(sizeof(KvqFinishState) + 256))) return rc;
+        KvqFinishState *d_st = s->d_finish.as<KvqFinishState>();
+        const size_t res_cap = kvq_result_layout(s->arena_cap, s->blob_cap).total + 256;
+        if ((rc = s->d_result.ensure(res_cap))) return rc;
+        // file positions of this scan lie in [lo, hi)
+        int64_t lo = 0, hi = 1;
+        for (size_t b = 0; b < s->batches.size(); b++) {
+            const int64_t a = s->batches[b].fpos_base, e = a + s->batches[b].nbytes;
+            if (b == 0 || a < lo) lo = a;
+            if (b == 0 || e > hi) hi = e;
+        }
+        const size_t nb0 = s->batches.size();
+        hipLaunchKernelGGL(kvq_finish_plan, dim3(1), dim3(64), 0, s->stream, (const unsigned int *)s->d_arena_n, s->arena_cap,
+                           (const unsigned long long *)s->d_blob_n, (unsigned long long)s->blob_cap, (const unsigned long long *)s->d_err,
+                           (long long)lo, (long long)hi, nb_max, d_st);
+        if (t->nseq > 0)
+            hipLaunchKernelGGL(kvq_cov_apply, dim3((uint32_t)((t->nseq + 3) / 4)), dim3(256), 0, s->stream, make_params(s));
+        if (!no_buckets &&
+            (rc = kvq_order_by_buckets(s->stream, s->d_arena.as<KvqHit>(), s->d_blob.as<uint8_t>(), s->blob_cap, d_st, W, s->d_result.as<uint8_t>()))) return rc;
+        hipLaunchKernelGGL(kvq_publish_small, dim3(1), dim3(256), 0, s->stream, (const unsigned int *)s->d_small.p,
+                           (const unsigned int *)s->d_fail, (unsigned int)nb0, (const unsigned int *)d_st, (unsigned int)(sizeof(KvqFinishState) / 4),
+                           (unsigned int *)small, fail, (unsigned int *)(s->pin_small + 64 + 4 * (size_t)KVQ_MAX_BATCHES));
+        KVQ_HIP(hipGetLastError());
+        // results: as many bytes as the last scan of this handle had (a guess: what is missing is fetched below)
+        size_t spec = std::min(s->spec_bytes, res_cap);
+        if (ctr_b + spec > s->pin_cap) spec = s->pin_cap > ctr_b ? s->pin_cap - ctr_b : 0;
+        KVQ_HIP(hipMemcpyAsync(s->pin, s->d_ctr, (size_t)t->ctr_len * 8, hipMemcpyDeviceToHost, s->stream));
+        if (spec) KVQ_HIP(hipMemcpyAsync(s->pin + ctr_b, s->d_result.p, spec, hipMemcpyDeviceToHost, s->stream));
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        const double t1 = now_ms();
+
+        // batches whose seed-filter pass failed validation (a tile's speculated record split disagreed with the
+        // newline count, one read flooded a wave's queues) were rolled back on the device: scan those again with
+        // the exhaustive kernels (device batches only; host batches were redone on the spot) and finish again
+        if (nb0 && (s->path_bits & 1)) {
+            bool any = false;
+            for (size_t b = 0; b < nb0; b++) {
+                if (!fail[b] || s->batches[b].redone || !s->batches[b].d_data) continue;
+                s->batches[b].redone = true;
+                s->tile_bytes = kvq_choose_tile(1u << 20, 0); s->rec_bytes = 0;   // (a record may have outgrown the look-ahead: back to the full one)
+                Batch again = s->batches[b]; again.is_redo = true;
+                s->batches.push_back(again);
+                s->path_bits |= 4; any = true;
+                rc = run_batch(s, again.d_data, again.nbytes, again.chunk_off.data(), (int64_t)again.chunk_off.size() - 1,
+                               again.fpos_base, s->batches.size() - 1, true);
+                if (rc) return rc;
+            }
+            if (any) continue;
+        }
+        const KvqFinishState st = *h_st;
+        const uint32_t n_hits = st.n_raw; const unsigned long long blob_n = st.blob_n, err = st.err;
+        if (err != ~0ull) {
+            // first malformed record in stream order (workhorse.c:1037-1048)
+            const long fpos = (long)(err >> 16); const int kind = (int)((err >> 8) & 0xFF); const int ch = (int)(err & 0xFF);
+            if (kind == 0) kvq_set_error(KVQ_ERR_FORMAT, "record must start with '@' (and not '%c') fpos=%ld", ch, fpos);
+            else kvq_set_error(KVQ_ERR_FORMAT, "3rd line of record must start with '+' fpos=%ld", fpos);
+            return KVQ_ERR_FORMAT;
+        }
+        if (n_hits > s->arena_cap || blob_n > s->blob_cap) {
+            // grow to what this scan needs and ask for a rescan
+            const uint64_t want_hits = std::max<uint64_t>(n_hits + n_hits / 8 + 1024, s->arena_cap);
+            // blob_n undercounts when the arena overflowed (dropped hits were never folded): scale it
+            uint64_t want_blob = blob_n;
+            if (n_hits > s->arena_cap && s->arena_cap) want_blob = (uint64_t)((double)blob_n * ((double)n_hits / s->arena_cap) * 1.25) + (1 << 20);
+            want_blob = std::max<uint64_t>(want_blob + want_blob / 8, s->blob_cap);
+            rc = ensure_arena(s, want_hits, want_blob); if (rc) return rc;
+            return KVQ_NEED_RESCAN;
+        }
+        const KvqResultLayout L = st.L;
+        if (ctr_b + L.total > s->pin_cap) {
+            // (a larger landing buffer: the counters, already there, move over)
+            const size_t want = (ctr_b + L.total) * 5 / 4 + (1 << 20);
+            uint8_t *np = nullptr;
+            if (hipHostMalloc((void **)&np, want, hipHostMallocDefault) != hipSuccess) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); return KVQ_ERR_MEMORY; }
+            memcpy(np, s->pin, ctr_b);
+            (void)hipHostFree(s->pin);
+            s->pin = np; s->pin_cap = want; spec = 0;
+        }
+        bool refetch = L.total > spec;
+        if (n_hits && (no_buckets || st.crowded)) {
+            // crowded buckets (or the comparison sort asked for): order the hits with the merge sort instead
+            if ((rc = kvq_order_by_mergesort(s->stream, s->d_arena.as<KvqHit>(), n_hits, s->d_blob.as<uint8_t>(), s->blob_cap, d_st,
+                                             s->d_sort_tmp, s->d_sorted, s->d_result.as<uint8_t>()))) return rc;
+            refetch = true;
+        }
+        if (n_hits && refetch) {
+            KVQ_HIP(hipMemcpyAsync(s->pin + ctr_b, s->d_result.p, L.total, hipMemcpyDeviceToHost, s->stream));
+            KVQ_HIP(hipStreamSynchronize(s->stream));
+        }
+        memcpy(s->h_ctr.data(), s->pin, (size_t)t->ctr_len * 8);
+        s->pin_res = s->pin + ctr_b;
+        if (!n_hits) memset(s->pin_res + L.hitseq_off, 0, 8);
+        s->res = L; s->n_hits = n_hits;
+        s->spec_bytes = L.total + L.total / 8 + 65536;
+
+        s->ms_all = s->ms_main = 0;
+        for (auto &e : s->ev_all) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_all += ms; }
+        for (auto &e : s->ev_main) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_main += ms; }
+        s->finished = true;
+        if (g_timing) fprintf(stderr, "finish: enqueue + wait %.3f  rest %.3f ms (%u hits)\n", t1 - t0, now_ms() - t1, n_hits);
+        return KVQ_OK;
+    }
+    kvq_set_error(KVQ_ERR_RUNTIME, "a redone batch failed validation again");
+    return KVQ_ERR_RUNTIME;
 }
 
 // returns KVQ_OK, an error code, or KVQ_NEED_RESCAN when host batches must be fed again
@@ -703,13 +729,13 @@ extern "C" int32_t kvq_scan_finish(kvq_scan *s)
 }
 
 extern "C" int64_t kvq_scan_n_hits(const kvq_scan *s) { return (int64_t)s->n_hits; }
-extern "C" const int32_t *kvq_scan_hit_seq_nr(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin + s->res.seq_nr); }
-extern "C" const int64_t *kvq_scan_hit_file_pos(const kvq_scan *s) { return reinterpret_cast<const int64_t *>(s->pin + s->res.file_pos); }
-extern "C" const int32_t *kvq_scan_hit_seq_pos(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin + s->res.seq_pos); }
-extern "C" const int32_t *kvq_scan_hit_length(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin + s->res.length); }
-extern "C" const int32_t *kvq_scan_hit_readlength(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin + s->res.readlength); }
-extern "C" const uint8_t *kvq_scan_hitseq_blob(const kvq_scan *s) { return s->pin + s->res.blob; }
-extern "C" const int64_t *kvq_scan_hitseq_offsets(const kvq_scan *s) { return reinterpret_cast<const int64_t *>(s->pin + s->res.hitseq_off); }
+extern "C" const int32_t *kvq_scan_hit_seq_nr(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin_res + s->res.seq_nr); }
+extern "C" const int64_t *kvq_scan_hit_file_pos(const kvq_scan *s) { return reinterpret_cast<const int64_t *>(s->pin_res + s->res.file_pos); }
+extern "C" const int32_t *kvq_scan_hit_seq_pos(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin_res + s->res.seq_pos); }
+extern "C" const int32_t *kvq_scan_hit_length(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin_res + s->res.length); }
+extern "C" const int32_t *kvq_scan_hit_readlength(const kvq_scan *s) { return reinterpret_cast<const int32_t *>(s->pin_res + s->res.readlength); }
+extern "C" const uint8_t *kvq_scan_hitseq_blob(const kvq_scan *s) { return s->pin_res + s->res.blob; }
+extern "C" const int64_t *kvq_scan_hitseq_offsets(const kvq_scan *s) { return reinterpret_cast<const int64_t *>(s->pin_res + s->res.hitseq_off); }
 extern "C" const int64_t *kvq_scan_counters(const kvq_scan *s) { return s->h_ctr.data(); }
 extern "C" void *kvq_scan_device_counters(const kvq_scan *s) { return s->d_ctr; }
 extern "C" int64_t kvq_scan_parsed(const kvq_scan *s) { return s->parsed; }

@@ -17,7 +17,7 @@ def main():
                 rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     rows.sort()
     # the last 4 main launches and everything between the first of them and the end of the step
-    mains = [i for i, r in enumerate(rows) if 'kvq_scan_seeded' in r[2]]
+    mains = [i for i, r in enumerate(rows) if ('kvq_scan_seeded' in r[2] or 'kvq_scan_bp' in r[2])]
     if len(mains) < 4:
         print('too few launches'); return
     lo = mains[-int(sys.argv[2]) if len(sys.argv) > 2 else -2]
