@@ -169,8 +169,10 @@ int64_t kvq_scan_main_kernel_launches(const kvq_scan *s);
 /* forget accumulated hits/counters/timers but keep buffers (bench steps) */
 int32_t kvq_scan_reset(kvq_scan *s);
 /* which kernels produced the result: bit 0 = the seed-filter kernel ran, bit 1 = the
- * exhaustive kernels ran, bit 2 = a seed-filter pass was discarded (its speculated
- * record split failed validation or a record outgrew the tile) and the data rescanned */
+ * exhaustive kernels ran, bit 2 = the seed-filter pass of a batch was discarded (its speculated
+ * record split failed validation, one read flooded a wave's queues) and the batch rescanned,
+ * bit 3 = tiles of the seed-filter pass left their records alone (a record longer than a tile's
+ * look-ahead, more newlines than its tables hold) and those records were scanned again */
 int32_t kvq_scan_path(const kvq_scan *s);
 /* 0 = let the table decide, 1 = force the exhaustive kernel for every sequence */
 void    kvq_scan_force_exhaustive(kvq_scan *s, int32_t on);

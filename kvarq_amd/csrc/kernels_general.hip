@@ -122,6 +122,46 @@ kvq_index_records(const uint8_t *__restrict__ data, const uint32_t *__restrict__
     }
 }
 
+// The records of tiles that the fused scan kernel has skipped (kernels_seeded.hip, TR_FLAG_SKIPPED): one wave
+// per tile walks the text from the tile's first owned byte and finds, from the exact number of newlines of the
+// chunk in front of the tile, the records that start behind a newline the tile owns (tile 0 of a chunk: also
+// the chunk's first record) -- the rule of the fused kernels -- with their four newlines, wherever those
+// lie (a record may run to the end of the chunk).  nl4 / rec_start as kvq_index_records writes them.
+struct KvqSkippedTile { uint32_t a, b, own_begin, own_end, seen, first; };
+
+extern "C" __global__ void __launch_bounds__(256)
+kvq_collect_skipped(const uint8_t *__restrict__ data, const KvqSkippedTile *__restrict__ tiles, uint32_t ntiles,
+                    uint32_t *__restrict__ nl4, uint32_t *__restrict__ rec_start, unsigned int *__restrict__ rec_count, uint32_t rec_cap)
+{
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (w >= ntiles) return;
+    const int lane = kvq_lane();
+    const KvqSkippedTile T = tiles[w];
+    uint32_t idx = T.seen;                       // number (within the chunk) of the next newline met
+    bool collecting = T.first != 0u;             // tile 0: the chunk's first record
+    uint32_t rstart = T.a, cnt = 0, nlb[4] = { 0, 0, 0, 0 };
+    for (uint32_t p = T.own_begin; p < T.b; p += 64u) {
+        if (p >= T.own_end && !collecting) break;
+        const bool is_nl = p + (uint32_t)lane < T.b && data[p + (uint32_t)lane] == '\n';
+        unsigned long long m = __ballot(is_nl);
+        while (m) {                              // (the same for every lane: the mask is the wave's)
+            const uint32_t pos = p + (uint32_t)(__ffsll((long long)m) - 1); m &= m - 1ull;
+            if (collecting) {
+                nlb[cnt++] = pos;
+                if (cnt == 4u) {
+                    if (lane == 0) {
+                        const unsigned int r = atomicAdd(rec_count, 1u);
+                        if (r < rec_cap) { rec_start[r] = rstart; nl4[4 * (size_t)r] = nlb[0]; nl4[4 * (size_t)r + 1] = nlb[1]; nl4[4 * (size_t)r + 2] = nlb[2]; nl4[4 * (size_t)r + 3] = nlb[3]; }
+                    }
+                    collecting = false;
+                }
+            }
+            if ((idx & 3u) == 3u && pos < T.own_end) { collecting = true; rstart = pos + 1u; cnt = 0; }     // (an owned newline that ends a record: the next one starts behind it)
+            idx++;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // quality trim
 // ---------------------------------------------------------------------------
@@ -248,7 +288,7 @@ kvq_match_all(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, 
     const int64_t fpos = fpos_base + read_off[g];
     const int mo = P.minoverlap, me = P.maxerrors;
 
-    for (int q = 0; q < nlist; q++) {
+    for (int q = (int)blockIdx.y; q < nlist; q += (int)gridDim.y) {      // (gridDim.y > 1: the sequences of a read shared out, for a few long reads)
         const int s = seq_list[q];
         const uint8_t *seq = P.tab + P.tab_off[s];
         const int seql = P.tab_off[s + 1] - P.tab_off[s];

@@ -51,7 +51,7 @@ struct kvq_table {
     std::vector<int32_t> seeded;         // sequences the seed-filter kernel serves
     std::vector<uint8_t> is_seeded;
     int32_t seed_k = 0;
-    DevBuf d_tab, d_off, d_exh, d_all;
+    DevBuf d_tab, d_off, d_exh, d_all, d_seeded;
     struct SeedIndex *index = nullptr;   // kernels_seeded
     int64_t ctr_len, off_nseqhits, off_nseqbasehits, off_cov, off_mut;
 };
@@ -65,7 +65,10 @@ struct Batch {
     const uint8_t *d_data; int64_t nbytes; int64_t fpos_base;
     std::vector<int64_t> chunk_off;
     bool redone = false;      // its seed-filter pass failed validation; an exhaustive redo batch follows
-    bool is_redo = false;     // this batch is such a redo
+    bool is_redo = false;     // this batch is such a redo (or the redo of another batch's skipped tiles)
+    bool skips_done = false;  // its skipped tiles have been scanned again
+    size_t skip_at = 0;       // its list of skipped tiles in the table pool
+    uint32_t tile_bytes = 0;  // bytes a tile owned when it was scanned
 };
 
 struct kvq_scan {
@@ -76,7 +79,7 @@ struct kvq_scan {
     unsigned long long *d_ctr = nullptr; bool own_ctr = false;
     std::vector<int64_t> h_ctr;
     // per-batch scratch
-    DevBuf d_chunk_off, d_seg_base, d_seg_cnt, d_chunk_nrec, d_rec_base, d_nl4, d_rec_start, d_read_off, d_read_len;
+    DevBuf d_skipped, d_chunk_off, d_seg_base, d_seg_cnt, d_chunk_nrec, d_rec_base, d_nl4, d_rec_start, d_read_off, d_read_len;
     // hit arena
     DevBuf d_covdiff;                  // coverage marks (KvqParams::covdiff)
     uint32_t tile_bytes = 0;           // bytes a tile of the seed-filter kernel owns (0 = not chosen yet; kvq_choose_tile)
@@ -88,6 +91,7 @@ struct kvq_scan {
     int path_bits = 0;
     std::vector<int64_t> cur_chunk_off;  // chunk offsets of the batch being enqueued
     size_t cur_co_at = 0;                // ... and where run_batch put them in the pool
+    size_t cur_skip_at = 0, cur_first_at = 0; uint32_t cur_ntiles = 0;   // the batch's list of skipped tiles, its first-tile table
     TablePool pool;
     // staging for host batches
     DevBuf d_stage;

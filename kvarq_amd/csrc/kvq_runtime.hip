@@ -70,16 +70,20 @@ int TablePool::reserve(size_t bytes, hipStream_t stream)
 {
     bytes = (bytes + 4095) & ~(size_t)4095;
     if (used + bytes <= cap) return KVQ_OK;
-    // grow: earlier batches may still read the old blocks, so wait for them first
+    // grow: earlier batches may still read the old blocks, so wait for them first; what they have left there
+    // (tile reports, lists of skipped tiles: found again by their offsets) moves over
     if (stream) KVQ_HIP(hipStreamSynchronize(stream));
-    const size_t want = std::max<size_t>(2 * cap, std::max<size_t>(bytes, (size_t)8 << 20));
-    release();
-    if (hipHostMalloc((void **)&h, want, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d, want) != hipSuccess) {
-        release();
+    const size_t want = std::max<size_t>(2 * cap, std::max<size_t>(used + bytes, (size_t)8 << 20));
+    uint8_t *nh = nullptr, *nd = nullptr;
+    if (hipHostMalloc((void **)&nh, want, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&nd, want) != hipSuccess) {
+        if (nh) (void)hipHostFree(nh);
         kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate %zu bytes of batch tables", want);
         return KVQ_ERR_MEMORY;
     }
-    cap = want; used = 0;
+    if (used) { memcpy(nh, h, used); KVQ_HIP(hipMemcpy(nd, d, used, hipMemcpyDeviceToDevice)); }
+    const size_t keep = used;
+    release();
+    h = nh; d = nd; cap = want; used = keep;
     return KVQ_OK;
 }
 void TablePool::release()
@@ -145,11 +149,13 @@ extern "C" kvq_table *kvq_table_create(const uint8_t *const *seqs, const int32_t
     std::vector<int32_t> all((size_t)nseq);
     for (int i = 0; i < nseq; i++) all[i] = i;
     bool ok = t->d_tab.ensure(t->h_tab.size()) == KVQ_OK && t->d_off.ensure((size_t)(nseq + 1) * 4) == KVQ_OK &&
-              t->d_exh.ensure((size_t)(nseq + 1) * 4) == KVQ_OK && t->d_all.ensure((size_t)(nseq + 1) * 4) == KVQ_OK;
+              t->d_exh.ensure((size_t)(nseq + 1) * 4) == KVQ_OK && t->d_all.ensure((size_t)(nseq + 1) * 4) == KVQ_OK &&
+              t->d_seeded.ensure((size_t)(nseq + 1) * 4) == KVQ_OK;
     if (ok) {
         ok = hipMemcpy(t->d_tab.p, t->h_tab.data(), t->h_tab.size(), hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(t->d_off.p, t->h_off.data(), (size_t)(nseq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
              (t->exhaustive.empty() || hipMemcpy(t->d_exh.p, t->exhaustive.data(), t->exhaustive.size() * 4, hipMemcpyHostToDevice) == hipSuccess) &&
+             (t->seeded.empty() || hipMemcpy(t->d_seeded.p, t->seeded.data(), t->seeded.size() * 4, hipMemcpyHostToDevice) == hipSuccess) &&
              (nseq == 0 || hipMemcpy(t->d_all.p, all.data(), (size_t)nseq * 4, hipMemcpyHostToDevice) == hipSuccess);
         if (!ok) kvq_set_error(KVQ_ERR_DEVICE, "uploading the sequence table failed");
     }
@@ -161,7 +167,7 @@ extern "C" void kvq_table_destroy(kvq_table *t)
 {
     if (!t) return;
     if (t->index) kvq_seed_index_destroy(t->index);
-    t->d_tab.release(); t->d_off.release(); t->d_exh.release(); t->d_all.release();
+    t->d_tab.release(); t->d_off.release(); t->d_exh.release(); t->d_all.release(); t->d_seeded.release();
     delete t;
 }
 extern "C" int32_t kvq_table_nseq(const kvq_table *t) { return t->nseq; }
@@ -195,7 +201,7 @@ extern "C" __global__ void __launch_bounds__(256)
 kvq_commit_batch(unsigned long long *stage, unsigned long long *ctr, unsigned long long *err_stage, unsigned long long *err,
                  const unsigned int *fail, unsigned int *arena_n, unsigned int *range)
 {
-    const bool bad = *fail != 0u;
+    const bool bad = (*fail & 1u) != 0u;          // (the bits above count skipped tiles: kvq_validate_tiles)
     for (int i = threadIdx.x; i < KVQ_STAGE_SLOTS; i += blockDim.x) {
         const unsigned long long v = stage[i];
         if (v && !bad) { if (i == KVQ_CTR_LONGEST_) atomicMax(&ctr[i], v); else atomicAdd(&ctr[i], v); }
@@ -313,7 +319,7 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     if (s->pin) (void)hipHostFree(s->pin);
     if (s->pin_small) (void)hipHostFree(s->pin_small);
     if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
-    DevBuf *bufs[] = { &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_order, &s->d_finish, &s->d_covdiff, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
+    DevBuf *bufs[] = { &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_order, &s->d_finish, &s->d_covdiff, &s->d_skipped, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
                        &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
     for (DevBuf *b : bufs) b->release();
     s->pool.release();
@@ -389,7 +395,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     // block, tile table and tile reports in kvq_seeded_launch, whose tiles own at least kvq_min_tile() bytes --
     // is made in one go: the pool must not move between the two)
     const size_t tiles_bound = (size_t)(nbytes / kvq_min_tile()) + (size_t)nchunks + 2;
-    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 8 + tiles_bound * 20 + 32768, s->stream))) return rc;
+    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 8 + tiles_bound * 20 + 49152, s->stream))) return rc;
     const size_t co_at = s->pool.take(((size_t)nchunks + 1) * 4);
     s->cur_co_at = co_at;
     uint32_t *co = reinterpret_cast<uint32_t *>(s->pool.h + co_at);
@@ -423,6 +429,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
         PS.ctr = s->d_stage_ctr; PS.err = s->d_err_stage;
         s->cur_fail = s->d_fail + batch_no;
         if ((rc = kvq_seeded_launch(s, PS, d_data, nbytes, d_co, nchunks, fpos_base, maxchunk))) return rc;
+        s->batches[batch_no].skip_at = s->cur_skip_at; s->batches[batch_no].tile_bytes = s->tile_bytes;
         KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
         s->main_launches++; s->path_bits |= 1;
         hist_done = true;
@@ -490,9 +497,102 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     return KVQ_OK;
 }
 
+// The records of the tiles that batch b's fused scan skipped (a record longer than the tile's look-ahead,
+// more newlines than a tile's tables hold): found again from the exact newline counts
+// (kvq_collect_skipped) and put through the exhaustive kernels for the seeded sequences -- a handful of
+// records instead of the whole batch.  Its hits form a batch of their own (appended to s->batches).
+static int redo_skipped(kvq_scan *s, size_t b, uint32_t nskip, const uint8_t *d_data)
+{
+    const kvq_table *t = s->t;
+    if (nskip > KVQ_SKIP_CAP) nskip = KVQ_SKIP_CAP;
+    const Batch src = s->batches[b];
+    std::vector<uint2> list(nskip);
+    KVQ_HIP(hipStreamSynchronize(s->stream));
+    KVQ_HIP(hipMemcpy(list.data(), s->pool.d + src.skip_at, (size_t)nskip * 8, hipMemcpyDeviceToHost));
+    // tile geometry as kvq_seeded_launch made it
+    const uint32_t TILE = src.tile_bytes;
+    const int64_t nchunks = (int64_t)src.chunk_off.size() - 1;
+    std::vector<uint32_t> first((size_t)nchunks + 1);
+    uint64_t acc = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        const uint32_t a = (uint32_t)src.chunk_off[c], e = (uint32_t)src.chunk_off[c + 1];
+        first[c] = (uint32_t)acc;
+        acc += e > a ? (uint32_t)(((uint64_t)e - (a & ~15u) + TILE - 1) / TILE) : 0u;
+    }
+    first[nchunks] = (uint32_t)acc;
+    std::vector<KvqSkippedTile> tiles(nskip);
+    for (uint32_t i = 0; i < nskip; i++) {
+        const uint32_t g = list[i].x;
+        const size_t c = (size_t)(std::upper_bound(first.begin(), first.end(), g) - first.begin()) - 1;
+        const uint32_t a = (uint32_t)src.chunk_off[c], e = (uint32_t)src.chunk_off[c + 1], tn = g - first[c];
+        const uint32_t g0 = (a & ~15u) + tn * TILE;
+        KvqSkippedTile T;
+        T.a = a; T.b = e; T.own_begin = tn == 0 ? a : g0; T.own_end = (uint64_t)g0 + TILE < e ? g0 + TILE : e;
+        T.seen = list[i].y; T.first = tn == 0 ? 1u : 0u;
+        tiles[i] = T;
+    }
+    // a record has four newlines: a tile of TILE bytes owns at most TILE / 4 of them
+    const uint32_t rec_cap = (uint32_t)std::min<uint64_t>((uint64_t)nskip * (TILE / 4u + 1u), 1u << 26);
+    int rc;
+    if ((rc = s->d_skipped.ensure((size_t)nskip * sizeof(KvqSkippedTile) + 64))) return rc;
+    if ((rc = s->d_nl4.ensure((size_t)rec_cap * 16))) return rc;
+    if ((rc = s->d_rec_start.ensure((size_t)rec_cap * 4))) return rc;
+    unsigned int *d_count = reinterpret_cast<unsigned int *>((char *)s->d_skipped.p + (((size_t)nskip * sizeof(KvqSkippedTile) + 15) & ~(size_t)15));
+    KVQ_HIP(hipMemcpyAsync(s->d_skipped.p, tiles.data(), (size_t)nskip * sizeof(KvqSkippedTile), hipMemcpyHostToDevice, s->stream));
+    KVQ_HIP(hipMemsetAsync(d_count, 0, 4, s->stream));
+    hipLaunchKernelGGL(kvq_collect_skipped, dim3((nskip + 3) / 4), dim3(256), 0, s->stream, d_data, s->d_skipped.as<KvqSkippedTile>(), nskip,
+                       s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(), d_count, rec_cap);
+    unsigned int R = 0;
+    KVQ_HIP(hipMemcpyAsync(&R, d_count, 4, hipMemcpyDeviceToHost, s->stream));
+    KVQ_HIP(hipStreamSynchronize(s->stream));
+    if (R > rec_cap) { kvq_set_error(KVQ_ERR_RUNTIME, "skipped tiles hold more records than a tile can"); return KVQ_ERR_RUNTIME; }
+    if (g_timing) {
+        fprintf(stderr, "redo_skipped: %u tiles, %u records\n", nskip, R);
+        for (uint32_t i = 0; i < nskip && i < 16; i++) fprintf(stderr, "  tile %u seen %u: chunk [%u, %u) owns [%u, %u) first %u\n", list[i].x, list[i].y, tiles[i].a, tiles[i].b, tiles[i].own_begin, tiles[i].own_end, tiles[i].first);
+    }
+    // the records' hits: a batch of their own
+    Batch again = src; again.is_redo = true; again.redone = false; again.skips_done = true;
+    s->batches.push_back(again);
+    const size_t batch_no = s->batches.size() - 1;
+    if (batch_no >= KVQ_MAX_BATCHES) { kvq_set_error(KVQ_ERR_RUNTIME, "too many batches in one scan"); return KVQ_ERR_RUNTIME; }
+    KvqParams P = make_params(s);
+    if (R > 0) {
+        if ((rc = s->d_read_off.ensure((size_t)R * 4))) return rc;
+        if ((rc = s->d_read_len.ensure((size_t)R * 4))) return rc;
+        hipLaunchKernelGGL(kvq_trim_records, dim3((R + 63) / 64), dim3(256), 0, s->stream, P, d_data, src.fpos_base, (uint32_t)R,
+                           s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(), s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), 1);
+        if (!t->seeded.empty())
+            // (few reads, some of them long: a read's sequences are shared out over up to 64 waves)
+            hipLaunchKernelGGL(kvq_match_all, dim3((R + 3) / 4, (uint32_t)std::min<size_t>(t->seeded.size(), 64)), dim3(256), 0, s->stream, P, d_data, src.fpos_base, (uint32_t)R,
+                               s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), t->d_seeded.as<int32_t>(), (int32_t)t->seeded.size());
+    }
+    KVQ_HIP(hipMemcpyAsync(s->d_range + batch_no + 1, s->d_arena_n, 4, hipMemcpyDeviceToDevice, s->stream));
+    hipLaunchKernelGGL(kvq_fold_batch, dim3(512), dim3(256), 0, s->stream, P, d_data, src.fpos_base,
+                       (const unsigned int *)(s->d_range + batch_no), (const unsigned int *)(s->d_range + batch_no + 1));
+    KVQ_HIP(hipGetLastError());
+    s->path_bits |= 8 | 2;
+    return KVQ_OK;
+}
+
+// what run_batch would reject, found out before the batch is put on the scan's list (a listed batch must
+// close its range of hits: one that was refused would leave a hole that the batches behind it fall into)
+static int check_batch(const void *data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, size_t batch_no, bool device)
+{
+    if (nbytes > 0xFFF00000ll) { kvq_set_error(KVQ_ERR_RUNTIME, "batch of %lld bytes is too large (< 4 GiB - 1 MiB)", (long long)nbytes); return KVQ_ERR_RUNTIME; }
+    if (batch_no >= KVQ_MAX_BATCHES) { kvq_set_error(KVQ_ERR_RUNTIME, "too many batches in one scan"); return KVQ_ERR_RUNTIME; }
+    if (device && ((uintptr_t)data & 15u) != 0) { kvq_set_error(KVQ_ERR_RUNTIME, "device buffer must be 16-byte aligned"); return KVQ_ERR_RUNTIME; }
+    for (int64_t c = 0; c <= nchunks; c++)
+        if (chunk_off[c] < 0 || chunk_off[c] > nbytes || (c && chunk_off[c] < chunk_off[c - 1])) {
+            kvq_set_error(KVQ_ERR_RUNTIME, "bad chunk offsets"); return KVQ_ERR_RUNTIME;
+        }
+    return KVQ_OK;
+}
+
 extern "C" int32_t kvq_scan_device(kvq_scan *s, const void *d_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base)
 {
     kvq_clear_error();
+    if (nbytes <= 0 || nchunks <= 0) return KVQ_OK;                  // nothing to scan: not a batch
+    int rc = check_batch(d_data, nbytes, chunk_off, nchunks, s->batches.size(), true); if (rc) return rc;
     Batch b; b.d_data = (const uint8_t *)d_data; b.nbytes = nbytes; b.fpos_base = fpos_base;
     b.chunk_off.assign(chunk_off, chunk_off + nchunks + 1);
     s->batches.push_back(b);
@@ -513,6 +613,14 @@ extern "C" int32_t kvq_scan_host_drain(kvq_scan *s)
     if (!(s->path_bits & 1)) return KVQ_OK;
     const unsigned int fail = *reinterpret_cast<const unsigned int *>(s->pin_small + 40);     // copied behind the batch
     if (!fail) return KVQ_OK;
+    if (!(fail & 1u)) {
+        // only some tiles were skipped: their records again, while the text is still in the staging buffer
+        s->batches[b].skips_done = true;
+        int rc = redo_skipped(s, b, fail >> 8, s->d_stage.as<uint8_t>());
+        if (rc) return rc;
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        return KVQ_OK;
+    }
     s->batches[b].redone = true;
     s->tile_bytes = kvq_choose_tile(1u << 20, 0); s->rec_bytes = 0;  // (a record may have outgrown the look-ahead: back to the full one)
     Batch again = s->batches[b]; again.is_redo = true;
@@ -530,8 +638,9 @@ extern "C" int32_t kvq_scan_host_drain(kvq_scan *s)
 extern "C" int32_t kvq_scan_host_async(kvq_scan *s, const void *h_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base)
 {
     kvq_clear_error();
-    if (nbytes <= 0) return KVQ_OK;
+    if (nbytes <= 0 || nchunks <= 0) return KVQ_OK;
     int rc = kvq_scan_host_drain(s); if (rc) return rc;          // the staging buffer and the table pool are free again
+    if ((rc = check_batch(h_data, nbytes, chunk_off, nchunks, s->batches.size(), false))) return rc;
     s->pool.used = 0;
     *reinterpret_cast<unsigned int *>(s->pin_small + 40) = 0;    // "speculation failed" of the batch about to be enqueued
     if (s->tile_bytes == 0)                                      // size the seed-filter tiles from the head of the text
@@ -627,7 +736,15 @@ static int finish_once(kvq_scan *s)
         if (nb0 && (s->path_bits & 1)) {
             bool any = false;
             for (size_t b = 0; b < nb0; b++) {
-                if (!fail[b] || s->batches[b].redone || !s->batches[b].d_data) continue;
+                if (!fail[b] || s->batches[b].redone || s->batches[b].is_redo || !s->batches[b].d_data) continue;
+                if (!(fail[b] & 1u)) {
+                    // only some tiles were skipped: their records again
+                    if (s->batches[b].skips_done) continue;
+                    s->batches[b].skips_done = true;
+                    if ((rc = redo_skipped(s, b, fail[b] >> 8, s->batches[b].d_data))) return rc;
+                    any = true;
+                    continue;
+                }
                 s->batches[b].redone = true;
                 s->tile_bytes = kvq_choose_tile(1u << 20, 0); s->rec_bytes = 0;   // (a record may have outgrown the look-ahead: back to the full one)
                 Batch again = s->batches[b]; again.is_redo = true;
@@ -710,7 +827,7 @@ int kvq_scan_finish_internal(kvq_scan *s)
         s->pool.used = 0;
         for (size_t b = 0; b < again.size(); b++) {
             if (again[b].is_redo) continue;            // the exhaustive redo of a failed batch: its original is replayed and judged afresh
-            Batch nb = again[b]; nb.redone = false;
+            Batch nb = again[b]; nb.redone = false; nb.skips_done = false;
             s->batches.push_back(nb);
             rc = run_batch(s, nb.d_data, nb.nbytes, nb.chunk_off.data(), (int64_t)nb.chunk_off.size() - 1, nb.fpos_base, s->batches.size() - 1, false);
             if (rc) return rc;

@@ -147,7 +147,7 @@ class Scanner(object):
         out['coverage'] = ctr[t.off_coverage:t.off_coverage + t.bases]
         out['mutations'] = ctr[t.off_mutations:t.off_mutations + 6 * t.bases]
         path = L.kvq_scan_path(self.h)
-        out['path'] = {'seeded': bool(path & 1), 'exhaustive': bool(path & 2), 'rescanned': bool(path & 4)}
+        out['path'] = {'seeded': bool(path & 1), 'exhaustive': bool(path & 2), 'rescanned': bool(path & 4), 'tiles_rescanned': bool(path & 8)}
         return out
 
     def reset(self):
