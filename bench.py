@@ -141,11 +141,24 @@ def main():
         batches.append((base, int(offs[j]) - base, (offs[i:j + 1] - base).copy()))
 
     table = scan.Table(seqs, **cfg)
+    ctr = None
+    reduce_by = None
     if world > 1:
-        ctr = torch.zeros(table.counters_len, dtype=torch.int64, device='cuda')
-        scanner = scan.Scanner(table, ctr.data_ptr())
+        # the join of the ranks: libkvarq_hip.so's own RCCL communicator (include/kvarq_hip.h, "several GPUs") --
+        # `finish` then sums the counter arrays of all ranks with one all-reduce on the scan's stream.  Should the
+        # library fail to make its communicator, the same sum is taken by torch.distributed (also RCCL) and the
+        # JSON line says so.
+        try:
+            comm = kdist.NativeComm.from_torch(dist, device='cuda' if backend == 'nccl' else None)
+            scanner = scan.Scanner(table)
+            scanner.set_comm(comm)
+            reduce_by = 'libkvarq_hip (RCCL all-reduce inside kvq_scan_finish)'
+        except Exception as e:                       # noqa: BLE001
+            sys.stderr.write('bench.py: native communicator unavailable (%s): reducing with torch.distributed\n' % e)
+            ctr = torch.zeros(table.counters_len, dtype=torch.int64, device='cuda')
+            scanner = scan.Scanner(table, ctr.data_ptr())
+            reduce_by = 'torch.distributed all_reduce (RCCL)'
     else:
-        ctr = None
         scanner = scan.Scanner(table)
     if args.exhaustive:
         scanner.force_exhaustive(True)
@@ -155,7 +168,7 @@ def main():
         for base, nbytes, co in batches:
             scanner.scan_device(d_data.ptr + base, nbytes, co, fpos_base=fpos0 + base)
         r = scanner.finish(hits=False, stats=False)     # hits, hit bytes and counters are on the host (C arrays); no Python tuples or dicts here
-        if world > 1:
+        if ctr is not None:
             kdist.reduce_counters(ctr, dist)                            # hit/coverage arrays over xGMI (one sum all-reduce)
             torch.cuda.current_stream().synchronize()                   # the next step zeroes ctr on the scan's own stream
         return r
@@ -187,13 +200,18 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        total_records = int(ctr[_lib.CTR_RECORDS].item())
-        total_hits = int(ctr[_lib.CTR_HITS].item())
+        if ctr is not None:
+            total_records = int(ctr[_lib.CTR_RECORDS].item())
+            total_hits = int(ctr[_lib.CTR_HITS].item())
+            assert int(r['counters'][_lib.CTR_RECORDS]) == n, 'records lost: %d of %d' % (int(r['counters'][_lib.CTR_RECORDS]), n)
+        else:                                        # (the library's host copy of the counters is the sum over all ranks)
+            total_records = int(r['counters'][_lib.CTR_RECORDS])
+            total_hits = int(r['counters'][_lib.CTR_HITS])
+        assert total_records == world * n, 'records lost: %d of %d' % (total_records, world * n)
     else:
         total_records = int(r['counters'][_lib.CTR_RECORDS])
         total_hits = r['n_hits']
-    # (with several ranks r['counters'] is the rank's own view of the reduced device tensor's host copy: per-rank records)
-    assert int(r['counters'][_lib.CTR_RECORDS]) == n, 'records lost: %d of %d' % (int(r['counters'][_lib.CTR_RECORDS]), n)
+        assert total_records == n, 'records lost: %d of %d' % (total_records, n)
 
     if rank != 0:
         if world > 1:
@@ -213,14 +231,14 @@ def main():
                                '(%d templates, both strands = %d sequences, %d bases); e=2, minoverlap=25, minreadlength=25, Amin=\'.\''
                                % (n, L, rb, args.table, len(plus), len(seqs), sum(map(len, seqs))),
                    'reads_per_gpu': n, 'readlen': L, 'table': args.table, 'table_scale': args.table_scale,
-                   'parallelism': 'read-shard x%d, all-reduce of counter arrays' % world if world > 1 else 'single GPU',
+                   'parallelism': 'read-shard x%d, counter arrays summed by %s' % (world, reduce_by) if world > 1 else 'single GPU',
                    'kernel_path': 'exhaustive' if args.exhaustive or not any(table.seeded) else
                                   'seed-filter k=%d (%d of %d sequences)' % (table.seed_k, sum(table.seeded), table.nseq),
                    'hits_per_step': total_hits, 'records_per_step': total_records,
                    'preheat_steps': max(0, args.preheat)},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                     'kernel': 'kvq_scan_seeded' if any(table.seeded) and not args.exhaustive else 'kvq_match_all',
+                     'kernel': ('kvq_scan_seeded' if os.environ.get('KVQ_KERNEL') == 'v1' else 'kvq_scan_bp') if any(table.seeded) and not args.exhaustive else 'kvq_match_all',
                      'launches_per_step': launches // max(1, args.steps), 'avg_launch_ms': main_avg_ms,
                      'algorithmic_bytes_per_launch': bytes_per_launch,
                      'all_kernels_ms_per_step': kern_ms / args.steps},
@@ -240,8 +258,14 @@ def main():
             continue
         if (pmc.get('reads_per_gpu') == n and pmc.get('kernel') == out['roofline']['kernel'] and
                 pmc.get('launches_per_step') == out['roofline']['launches_per_step']):
-            out['roofline']['traffic'] = pmc['hbm_bytes_per_launch']
-            out['roofline']['traffic_source'] = 'profiles/' + os.path.basename(path)
+            # counters measured on OTHER code say nothing about this run: the file carries the hash of the
+            # kernel sources it was measured on, and only the same sources may quote it
+            if pmc.get('source_sha256') == source_sha256():
+                out['roofline']['traffic'] = pmc['hbm_bytes_per_launch']
+                out['roofline']['traffic_source'] = 'profiles/' + os.path.basename(path)
+            else:
+                out['roofline']['traffic_note'] = 'profiles/%s was measured on other kernel sources (%s): not quoted' % (
+                    os.path.basename(path), str(pmc.get('source_sha256'))[:12])
             break
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(g, seqs, cfg, L, rb, args.cpu_seconds)
@@ -249,6 +273,20 @@ def main():
     sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+
+
+def source_sha256():
+    """hash of the sources libkvarq_hip.so is built from (kvarq_amd/csrc, include/): what a PMC measurement under
+    profiles/ is tied to"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, 'kvarq_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'kvarq_amd', 'csrc', '*.h')) +
+                       glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+        h.update(os.path.basename(path).encode())
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def cpu_baseline(g, seqs, cfg, L, rb, seconds):

@@ -37,7 +37,10 @@ enum {
     KVQ_ERR_MEMORY  = 3,   /* MemoryError  */
     KVQ_ERR_RUNTIME = 4,   /* RuntimeError */
     KVQ_ERR_TYPE    = 5,   /* TypeError    */
-    KVQ_ERR_DEVICE  = 6    /* no usable GPU / HIP failure: RuntimeError, never a CPU fallback */
+    KVQ_ERR_DEVICE  = 6,   /* no usable GPU / HIP failure: RuntimeError, never a CPU fallback */
+    KVQ_ERR_RESCAN  = 7    /* kvq_scan_finish after host batches: the hit arena was too small and has been enlarged;
+                            * kvq_scan_reset and feed the same batches again (kvq_findseqs does so itself;
+                            * device batches are replayed by the library).  kvarq_amd.scan.Scanner replays them. */
 };
 
 /* ---- engine.config / engine.get_config (workhorse.c:1484-1507) -------------
@@ -176,6 +179,34 @@ int32_t kvq_scan_reset(kvq_scan *s);
 int32_t kvq_scan_path(const kvq_scan *s);
 /* 0 = let the table decide, 1 = force the exhaustive kernel for every sequence */
 void    kvq_scan_force_exhaustive(kvq_scan *s, int32_t on);
+
+/* ---- several GPUs, one process each ----------------------------------------------------------
+ * The reference starts nthreads workers on one file and joins them into one result
+ * (workhorse.c:1375-1447: pthread_create / pthread_join, counters under mutexes, one hit list).
+ * Here every process scans its own stretch of the reads on its own GPU -- no exchange on the data
+ * path -- and the join is a collective over RCCL (librccl.so, loaded on first use):
+ *   kvq_comm_unique_id   rank 0 makes the 128-byte id of a communicator, the caller hands it to the
+ *                        other ranks (any way it likes: a file, MPI, torch.distributed ...)
+ *   kvq_comm_create      every rank, collectively, with its number and the id; after kvq_set_device
+ *   kvq_scan_set_comm    kvq_scan_finish then is collective: behind the rank's own finish the counter
+ *                        arrays of all ranks are summed (one all-reduce on the scan's stream; the slot
+ *                        of the longest read takes the maximum) on the device and in kvq_scan_counters
+ *   kvq_scan_gather_hits after kvq_scan_finish, collective: the hits of all ranks, in rank order --
+ *                        ranks scan consecutive stretches of the stream, so that is the reference's
+ *                        order -- replace the rank's own behind kvq_scan_n_hits / kvq_scan_hit_* /
+ *                        kvq_scan_hitseq_*: a count exchange (all-gather), then one broadcast per
+ *                        rank and array into its place
+ *   kvq_comm_allreduce_counters  the same sum for a counter array the caller keeps itself
+ *                        (d_scratch16: 16 bytes of device memory) */
+typedef struct kvq_comm kvq_comm;
+int32_t   kvq_comm_unique_id(void *id128);
+kvq_comm *kvq_comm_create(int32_t nranks, int32_t rank, const void *id128);
+void      kvq_comm_destroy(kvq_comm *c);
+int32_t   kvq_comm_nranks(const kvq_comm *c);
+int32_t   kvq_comm_rank(const kvq_comm *c);
+int32_t   kvq_scan_set_comm(kvq_scan *s, kvq_comm *c);
+int32_t   kvq_scan_gather_hits(kvq_scan *s, kvq_comm *c);
+int32_t   kvq_comm_allreduce_counters(kvq_comm *c, void *d_counters, int64_t ctr_len, void *d_scratch16);
 
 /* ---- engine.findseqs (workhorse.c:1249-1464) -------------------------------
  * files: plain or ".gz" (by suffix, workhorse.c:582), scanned as one stream

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PATH = os.path.join(HERE, 'libkvarq_hip.so')
 
 MAX_READLENGTH = 1024
-OK, ERR_FORMAT, ERR_IO, ERR_MEMORY, ERR_RUNTIME, ERR_TYPE, ERR_DEVICE = range(7)
+OK, ERR_FORMAT, ERR_IO, ERR_MEMORY, ERR_RUNTIME, ERR_TYPE, ERR_DEVICE, ERR_RESCAN = range(8)
 CTR_RECORDS, CTR_LONGEST, CTR_HITS, CTR_READLENGTHS = 0, 1, 2, 4
 
 
@@ -70,6 +70,14 @@ PROTOTYPES = {
     'kvq_scan_reset': (i32, [vp]),
     'kvq_scan_path': (i32, [vp]),
     'kvq_scan_force_exhaustive': (None, [vp, i32]),
+    'kvq_comm_unique_id': (i32, [vp]),
+    'kvq_comm_create': (vp, [i32, i32, vp]),
+    'kvq_comm_destroy': (None, [vp]),
+    'kvq_comm_nranks': (i32, [vp]),
+    'kvq_comm_rank': (i32, [vp]),
+    'kvq_scan_set_comm': (i32, [vp, vp]),
+    'kvq_scan_gather_hits': (i32, [vp, vp]),
+    'kvq_comm_allreduce_counters': (i32, [vp, vp, i64, vp]),
     'kvq_findseqs': (vp, [P(cp), i32, P(cp), P(i32), i32]),
     'kvq_findseqs_free': (None, [vp]),
     'kvq_host_chunk_plan': (i64, [P(cp), i32, P(i64), P(i64), i64, P(i64), P(i64), i64]),

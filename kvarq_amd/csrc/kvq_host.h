@@ -71,8 +71,12 @@ struct Batch {
     uint32_t tile_bytes = 0;  // bytes a tile owned when it was scanned
 };
 
+struct kvq_comm;
+int kvq_comm_reduce_counters(kvq_comm *c, unsigned long long *d_ctr, int64_t ctr_len, unsigned long long *d_scratch, hipStream_t stream);
+
 struct kvq_scan {
     const kvq_table *t = nullptr;
+    kvq_comm *comm = nullptr;            // several GPUs: `finish` sums the counters of all ranks over it (kvq_dist.hip)
     hipStream_t stream = nullptr;
     bool force_exhaustive = false;
     // counters

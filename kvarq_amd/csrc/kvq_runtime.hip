@@ -837,11 +837,31 @@ int kvq_scan_finish_internal(kvq_scan *s)
     return KVQ_ERR_MEMORY;
 }
 
+// several GPUs (kvq_scan_set_comm): the counters of all ranks summed over RCCL, on the device and in the host
+// copy.  `finish` is collective then: a rank whose own scan has failed still takes part, so that the others
+// do not wait for it for ever, and reports its error afterwards.
+static int reduce_over_ranks(kvq_scan *s)
+{
+    int rc;
+    if ((rc = s->d_finish.ensure(sizeof(KvqFinishState) + 256))) return rc;
+    unsigned long long *scratch = (unsigned long long *)((char *)s->d_finish.p + ((sizeof(KvqFinishState) + 15) & ~(size_t)15));
+    if ((rc = kvq_comm_reduce_counters(s->comm, s->d_ctr, s->t->ctr_len, scratch, s->stream))) return rc;
+    KVQ_HIP(hipMemcpyAsync(s->pin, s->d_ctr, (size_t)s->t->ctr_len * 8, hipMemcpyDeviceToHost, s->stream));
+    KVQ_HIP(hipStreamSynchronize(s->stream));
+    memcpy(s->h_ctr.data(), s->pin, (size_t)s->t->ctr_len * 8);
+    return KVQ_OK;
+}
+
 extern "C" int32_t kvq_scan_finish(kvq_scan *s)
 {
     kvq_clear_error();
     int rc = kvq_scan_finish_internal(s);
-    if (rc == KVQ_NEED_RESCAN) { kvq_set_error(KVQ_ERR_MEMORY, "hit arena overflow on host batches: rescan required"); return KVQ_ERR_MEMORY; }
+    if (rc == KVQ_NEED_RESCAN) { kvq_set_error(KVQ_ERR_RESCAN, "hit arena overflow on host batches: the arena has been enlarged, reset the scan and feed the batches again"); rc = KVQ_ERR_RESCAN; }
+    if (s->comm) {
+        const int saved = kvq_error_code(); char msg[1024]; kvq_last_error(msg, sizeof(msg));
+        const int rc2 = reduce_over_ranks(s);
+        if (rc) kvq_set_error(saved, "%s", msg); else rc = rc2;
+    }
     return rc;
 }
 

@@ -7,3 +7,4 @@
 #include "synth.hip"
 #include "kvq_runtime.hip"
 #include "kvq_findseqs.hip"
+#include "kvq_dist.hip"

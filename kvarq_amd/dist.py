@@ -9,7 +9,42 @@ longest-read slot, over RCCL/xGMI (``torch.distributed`` backend ``nccl``) --
 or ``gloo`` on CPUs in the tests.  Hit lists are variable-length and stay on
 their rank (gather them with ``gather_hits`` when a caller wants them all).
 """
+import ctypes as C
+
 from . import _lib
+
+
+class NativeComm(object):
+    """an RCCL communicator made by libkvarq_hip.so itself (include/kvarq_hip.h, "several GPUs"): what a C caller
+    of the library uses; ``Scanner.set_comm`` makes ``finish`` sum the counters of all ranks over it and
+    ``Scanner.gather_hits`` collects the hit arrays.  `exchange(id_or_None) -> id`: how rank 0's 128-byte id
+    reaches the other ranks (``from_torch`` broadcasts it with torch.distributed)."""
+
+    def __init__(self, world, rank, exchange):
+        L = _lib.lib()
+        buf = C.create_string_buffer(128)
+        if rank == 0 and L.kvq_comm_unique_id(buf) != 0:
+            raise RuntimeError(_lib.last_error()[1])
+        uid = exchange(buf.raw if rank == 0 else None)
+        self.h = L.kvq_comm_create(world, rank, C.create_string_buffer(bytes(uid), 128))
+        if not self.h:
+            raise RuntimeError(_lib.last_error()[1])
+        self.world, self.rank = world, rank
+
+    @classmethod
+    def from_torch(cls, dist, device=None):
+        import torch
+
+        def exchange(uid):
+            t = torch.zeros(128, dtype=torch.uint8, device=device) if uid is None else torch.tensor(list(uid), dtype=torch.uint8, device=device)
+            dist.broadcast(t, src=0)
+            return bytes(t.cpu().tolist())
+        return cls(dist.get_world_size(), dist.get_rank(), exchange)
+
+    def close(self):
+        if self.h:
+            _lib.lib().kvq_comm_destroy(self.h)
+            self.h = None
 
 
 def shard(n_items, rank, world):
@@ -29,13 +64,37 @@ def reduce_counters(ctr, dist, group=None):
     return ctr
 
 
-def gather_hits(hits, dist, group=None):
-    """all ranks' hit lists merged in canonical (stream) order: file_pos is global, so a
-    sort by (file_pos, seq_nr) of the per-rank canonical lists restores the reference's order
-    (ties inside one read keep their per-rank order: Python's sort is stable)"""
+def gather_hit_arrays(arrays, dist, group=None, device=None):
+    """every rank's hit arrays (``Scanner.hit_arrays``) in rank order = stream order (ranks scan consecutive
+    stretches, csrc/workhorse.c:1417-1431 builds one list): a count exchange, then one all-gather per array,
+    padded to the largest rank -- tensors, not pickled objects, so it runs over RCCL on device memory as well as
+    over gloo.  Returns the merged arrays (hitseq offsets rebased onto the merged bytes)."""
+    import numpy as np
+    import torch
     world = dist.get_world_size(group)
-    parts = [None] * world
-    dist.all_gather_object(parts, list(hits), group=group)
-    merged = [h for p in parts for h in p]
-    merged.sort(key=lambda h: (h[1], h[0]))
-    return merged
+    n, nb = len(arrays['seq_nr']), len(arrays['blob'])
+    counts = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([n, nb], dtype=torch.int64, device=device), group=group)
+    counts = [c.cpu().tolist() for c in counts]
+    out = {}
+    for key, width in (('seq_nr', 0), ('file_pos', 0), ('seq_pos', 0), ('length', 0), ('readlength', 0), ('blob', 1)):
+        m = max(c[width] for c in counts)
+        a = arrays[key]
+        pad = torch.zeros(max(m, 1), dtype=torch.from_numpy(a[:0].copy()).dtype, device=device)
+        pad[:len(a)] = torch.from_numpy(np.ascontiguousarray(a)).to(pad.device)
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        out[key] = np.concatenate([p[:c[width]].cpu().numpy() for p, c in zip(parts, counts)])
+    lens = np.maximum(out['length'], 0).astype(np.int64)
+    out['offsets'] = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    return out
+
+
+def hits_from_arrays(arrays):
+    """(hits, hitseqs) in the reference's shape from merged hit arrays"""
+    from .engine import Hit
+    n = len(arrays['seq_nr'])
+    hits = tuple(Hit(int(arrays['seq_nr'][i]), int(arrays['file_pos'][i]), int(arrays['seq_pos'][i]), int(arrays['length'][i]),
+                     int(arrays['readlength'][i])) for i in range(n))
+    blob, off = arrays['blob'].tobytes(), arrays['offsets']
+    return hits, [blob[off[i]:off[i + 1]] for i in range(n)]

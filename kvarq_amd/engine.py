@@ -71,12 +71,19 @@ def get_config():
             'nthreads': c.nthreads, 'Amin': chr(c.Amin & 0xFF), 'Azero': chr(c.Azero & 0xFF)}
 
 
+class RescanRequired(MemoryError):
+    """kvq_scan_finish after host batches: the hit arena was too small; it has been enlarged, and the same
+    batches have to be fed again after a reset (``scan.Scanner`` does that itself)"""
+
+
 def _raise_last():
     code, msg = _lib.last_error()
     if code == _lib.ERR_FORMAT:
         raise FastqFileFormatException(msg)
     if code == _lib.ERR_IO:
         raise IOError(msg)
+    if code == _lib.ERR_RESCAN:
+        raise RescanRequired(msg)
     if code == _lib.ERR_MEMORY:
         raise MemoryError(msg)
     if code == _lib.ERR_TYPE:

@@ -91,6 +91,19 @@ class Scanner(object):
         self.h = _lib.lib().kvq_scan_create(table.h, counters_ptr)
         if not self.h:
             _raise_last()
+        self._host_batches = []          # what scan_host was given since the last reset (fed again when the hit arena overflows)
+        self._comm = None
+
+    def set_comm(self, comm):
+        """several GPUs (``dist.NativeComm``): ``finish`` becomes collective and sums the counters of all ranks over RCCL"""
+        self._comm = comm
+        _check(_lib.lib().kvq_scan_set_comm(self.h, comm.h if comm is not None else None))
+
+    def gather_hits(self):
+        """collective, after ``finish(hits=False)``: every rank's hits, in rank (= stream) order, on every rank;
+        returns what ``finish`` returns for them"""
+        _check(_lib.lib().kvq_scan_gather_hits(self.h, self._comm.h if self._comm is not None else None))
+        return self._hits_dict()
 
     def force_exhaustive(self, on=True):
         _lib.lib().kvq_scan_force_exhaustive(self.h, 1 if on else 0)
@@ -102,6 +115,7 @@ class Scanner(object):
     def scan_host(self, data, chunk_off=None, fpos_base=0):
         arr = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         co = chunk_offsets(arr) if chunk_off is None else np.ascontiguousarray(chunk_off, dtype=np.int64)
+        self._host_batches.append((arr, co, fpos_base))
         _check(_lib.lib().kvq_scan_host(self.h, arr.ctypes.data if arr.nbytes else None, arr.nbytes,
                                         co.ctypes.data_as(C.POINTER(C.c_int64)), len(co) - 1, fpos_base))
 
@@ -112,23 +126,24 @@ class Scanner(object):
         also skips the Python ``stats`` dict and hands out ``counters`` as a view of the library's host
         array (valid until the next ``reset`` / ``close``) -- for callers that only reduce counters."""
         L = _lib.lib()
-        _check(L.kvq_scan_finish(self.h))
+        for attempt in range(4):
+            if L.kvq_scan_finish(self.h) == 0:
+                break
+            if _lib.last_error()[0] != _lib.ERR_RESCAN or attempt == 3:
+                _raise_last()
+            # the hit arena was too small for the host batches (it has been enlarged): feed them again
+            again = self._host_batches
+            self.reset()
+            for arr, co, fpos_base in again:
+                self.scan_host(arr, co, fpos_base)
         t = self.table
         ctr = _view(L.kvq_scan_counters(self.h), t.counters_len, C.c_int64, np.int64)
         if stats:
             ctr = ctr.copy()
         out = {'counters': ctr}
-        nh = L.kvq_scan_n_hits(self.h)
-        out['n_hits'] = nh
+        out['n_hits'] = L.kvq_scan_n_hits(self.h)
         if hits:
-            a = [_view(f(self.h), nh, ct, dt).copy()
-                 for f, ct, dt in ((L.kvq_scan_hit_seq_nr, C.c_int32, np.int32), (L.kvq_scan_hit_file_pos, C.c_int64, np.int64),
-                                   (L.kvq_scan_hit_seq_pos, C.c_int32, np.int32), (L.kvq_scan_hit_length, C.c_int32, np.int32),
-                                   (L.kvq_scan_hit_readlength, C.c_int32, np.int32))]
-            out['hits'] = tuple(Hit(int(a[0][i]), int(a[1][i]), int(a[2][i]), int(a[3][i]), int(a[4][i])) for i in range(nh))
-            off = L.kvq_scan_hitseq_offsets(self.h)
-            blob = C.string_at(L.kvq_scan_hitseq_blob(self.h), off[nh]) if nh else b''
-            out['hitseqs'] = [blob[off[i]:off[i + 1]] for i in range(nh)]
+            out.update(self._hits_dict())
         out['kernel_ms'] = L.kvq_scan_kernel_ms(self.h)
         out['main_kernel_ms'] = L.kvq_scan_main_kernel_ms(self.h)
         out['main_kernel_launches'] = L.kvq_scan_main_kernel_launches(self.h)
@@ -150,7 +165,34 @@ class Scanner(object):
         out['path'] = {'seeded': bool(path & 1), 'exhaustive': bool(path & 2), 'rescanned': bool(path & 4), 'tiles_rescanned': bool(path & 8)}
         return out
 
+    def hit_arrays(self):
+        """the library's result arrays as numpy arrays (copies): seq_nr, file_pos, seq_pos, length, readlength,
+        hitseq offsets (n + 1), hit bytes"""
+        L = _lib.lib()
+        nh = L.kvq_scan_n_hits(self.h)
+        a = [_view(f(self.h), nh, ct, dt).copy()
+             for f, ct, dt in ((L.kvq_scan_hit_seq_nr, C.c_int32, np.int32), (L.kvq_scan_hit_file_pos, C.c_int64, np.int64),
+                               (L.kvq_scan_hit_seq_pos, C.c_int32, np.int32), (L.kvq_scan_hit_length, C.c_int32, np.int32),
+                               (L.kvq_scan_hit_readlength, C.c_int32, np.int32))]
+        off = _view(L.kvq_scan_hitseq_offsets(self.h), nh + 1, C.c_int64, np.int64).copy()
+        blob = np.frombuffer(C.string_at(L.kvq_scan_hitseq_blob(self.h), int(off[nh])) if nh else b'', dtype=np.uint8)
+        return dict(seq_nr=a[0], file_pos=a[1], seq_pos=a[2], length=a[3], readlength=a[4], offsets=off, blob=blob)
+
+    def _hits_dict(self):
+        """the library's result arrays as the reference's ``hits`` tuple and ``hitseqs`` list"""
+        L = _lib.lib()
+        nh = L.kvq_scan_n_hits(self.h)
+        a = [_view(f(self.h), nh, ct, dt).copy()
+             for f, ct, dt in ((L.kvq_scan_hit_seq_nr, C.c_int32, np.int32), (L.kvq_scan_hit_file_pos, C.c_int64, np.int64),
+                               (L.kvq_scan_hit_seq_pos, C.c_int32, np.int32), (L.kvq_scan_hit_length, C.c_int32, np.int32),
+                               (L.kvq_scan_hit_readlength, C.c_int32, np.int32))]
+        hits = tuple(Hit(int(a[0][i]), int(a[1][i]), int(a[2][i]), int(a[3][i]), int(a[4][i])) for i in range(nh))
+        off = L.kvq_scan_hitseq_offsets(self.h)
+        blob = C.string_at(L.kvq_scan_hitseq_blob(self.h), off[nh]) if nh else b''
+        return {'n_hits': nh, 'hits': hits, 'hitseqs': [blob[off[i]:off[i + 1]] for i in range(nh)]}
+
     def reset(self):
+        self._host_batches = []
         _check(_lib.lib().kvq_scan_reset(self.h))
 
     def close(self):

@@ -97,15 +97,23 @@ def _rank_main(rank, world, port, tmp):
     ctr[o + 2 * nseq:o + 2 * nseq + bases] = torch.tensor(r['coverage'])
     ctr[o + 2 * nseq + bases:] = torch.tensor(r['mutations'])
     kdist.reduce_counters(ctr, dist)
-    hits = kdist.gather_hits([tuple(h) for h in r['hits']], dist)
+    # the hit lists: SoA arrays (what Scanner.hit_arrays hands out), a count exchange and one all-gather per array
+    import numpy as np
+    hs = r['hits']
+    arrays = dict(seq_nr=np.array([h[0] for h in hs], dtype=np.int32), file_pos=np.array([h[1] for h in hs], dtype=np.int64),
+                  seq_pos=np.array([h[2] for h in hs], dtype=np.int32), length=np.array([h[3] for h in hs], dtype=np.int32),
+                  readlength=np.array([h[4] for h in hs], dtype=np.int32),
+                  blob=np.frombuffer(b''.join(x if isinstance(x, bytes) else x.encode('latin-1') for x in r['hitseqs']), dtype=np.uint8))
+    merged = kdist.gather_hit_arrays(arrays, dist)
+    hits, hitseqs = kdist.hits_from_arrays(merged)
     if rank == 0:
-        torch.save({'ctr': ctr, 'hits': hits}, os.path.join(tmp, 'reduced.pt'))
+        torch.save({'ctr': ctr, 'hits': [tuple(h) for h in hits], 'hitseqs': hitseqs}, os.path.join(tmp, 'reduced.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_reduction_equals_single_scan(tmp_path):
-    """world_size 2 over gloo: sharded scans + reduce_counters/gather_hits == one scan of everything"""
+    """world_size 2 over gloo: sharded scans + reduce_counters / gather_hit_arrays == one scan of everything"""
     import torch
     import torch.multiprocessing as mp
     port = 29000 + os.getpid() % 2000
@@ -125,3 +133,4 @@ def test_two_rank_reduction_equals_single_scan(tmp_path):
     assert ctr[o + 2 * nseq:o + 2 * nseq + bases].tolist() == whole['coverage']
     assert ctr[o + 2 * nseq + bases:].tolist() == whole['mutations']
     assert [tuple(h) for h in got['hits']] == [tuple(h) for h in whole['hits']]
+    assert [x if isinstance(x, bytes) else x.encode('latin-1') for x in got['hitseqs']] == [x if isinstance(x, bytes) else x.encode('latin-1') for x in whole['hitseqs']]

@@ -386,6 +386,32 @@ def test_an_empty_or_refused_batch_leaves_no_hole():
     s.close(); t.close(); d.free(); d2.free()
 
 
+def test_native_rccl_communicator_of_one_rank():
+    """the library's own RCCL entry points (include/kvarq_hip.h, "several GPUs") on the one GPU there is: a
+    communicator of one rank; finish sums the counters over it (all-reduce, maximum for the longest read) and
+    gather_hits collects the hit arrays (all-gather of the counts, a broadcast per array) -- both must leave a
+    single rank's result as it is.  (More ranks need more GPUs: the two-rank logic runs over gloo on CPUs.)"""
+    from kvarq_amd import dist as kdist
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g))
+    host = synth.reads(g, 0, 20000, 150)
+    t = scan.Table(seqs, **cases.PRODUCT)
+    s = scan.Scanner(t)
+    s.scan_host(host)
+    alone = s.finish()
+    comm = kdist.NativeComm(1, 0, lambda uid: uid)
+    s.reset()
+    s.set_comm(comm)
+    s.scan_host(host)
+    r = s.finish()
+    assert r['n_hits'] == alone['n_hits'] > 30 and tuple(r['hits']) == tuple(alone['hits'])
+    assert r['counters'].tolist() == alone['counters'].tolist()
+    gathered = s.gather_hits()
+    assert tuple(gathered['hits']) == tuple(alone['hits']) and gathered['hitseqs'] == alone['hitseqs']
+    s.set_comm(None)
+    s.close(); t.close(); comm.close()
+
+
 def test_one_long_record_costs_its_tile_not_the_batch():
     """300 k ordinary reads with ONE 5 kB record in their middle: the record outgrows the look-ahead of the tile
     that owns it; only that tile's records go through the exhaustive kernels (path: tiles_rescanned, not

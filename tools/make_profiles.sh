@@ -21,7 +21,7 @@ step sq1;    timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAI
 step sq2;    timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/sq2 -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/sq2.log 2>&1
 cd $R
 python3 tools/pmc_traffic.py $O/fetch $O/write 10000000 325 > $O/pmc_traffic.json
-python3 tools/pmc_sum.py $O/sq1 > $O/pmc_sq_counters.txt; python3 tools/pmc_sum.py $O/sq2 >> $O/pmc_sq_counters.txt
+python3 tools/pmc_sum.py $O/sq1 kvq_scan_ > $O/pmc_sq_counters.txt; python3 tools/pmc_sum.py $O/sq2 kvq_scan_ >> $O/pmc_sq_counters.txt
 python3 tools/trace_step.py $O/stats 1 > $O/step_timeline.txt
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/rocprofv3_kernel_stats.csv 2>/dev/null
 step stamps; KVQ_DBG=16 timeout -k 10 200 python3 tools/phase_stamps.py > $O/phase_stamps.txt 2>&1
@@ -30,7 +30,7 @@ step phases
 for d in 0 1 2 32; do
   ( cd /tmp; KVQ_DBG=$d timeout -k 10 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/ph$d -- $BP --reads 5000000 --steps 2 --warmup 1 --no-cpu-baseline > $O/ph$d.log 2>&1 )
   echo "== KVQ_DBG=$d (0: whole kernel, 1: no verify, 2: no filter and verify, 32: front end only); 5 M reads per launch" >> $O/pmc_phases.txt
-  python3 tools/pmc_sum.py $O/ph$d >> $O/pmc_phases.txt
+  python3 tools/pmc_sum.py $O/ph$d kvq_scan_ >> $O/pmc_phases.txt
 done
 step configs
 : > $O/other_configs.txt

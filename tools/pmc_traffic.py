@@ -7,9 +7,10 @@ Both passes run the same command (`python bench.py --steps 2 --warmup 1 --no-cpu
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts half of the bytes of a
 16-byte-per-lane streaming read, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE * 1024 is exact.
 """
-import csv, glob, json, sys
+import csv, glob, json, os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-def per_launch(root, counter, sub='kvq_scan_seeded'):
+def per_launch(root, counter, sub='kvq_scan_'):
     acc = {}
     for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
         with open(f) as fh:
@@ -20,6 +21,12 @@ def per_launch(root, counter, sub='kvq_scan_seeded'):
 
 def main():
     fdir, wdir, reads, rb = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    import bench                                 # (source_sha256: the hash bench.py checks before it quotes this file)
+    kernel = 'kvq_scan_seeded' if os.environ.get('KVQ_KERNEL') == 'v1' else 'kvq_scan_bp'
+    try:
+        head = subprocess.check_output(['git', 'rev-parse', 'HEAD'], cwd=os.path.dirname(os.path.abspath(bench.__file__)), stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        head = None                              # (the GPU box has no .git: the source hash is what ties the file to the code)
     f = per_launch(fdir, 'FETCH_SIZE'); w = per_launch(wdir, 'WRITE_SIZE')
     steps = 3                                    # --steps 2 --warmup 1
     launches_per_step = len(f) // steps
@@ -28,7 +35,8 @@ def main():
     rd = 2.0 * fm * 1024.0; wr = wm * 1024.0
     out = {
         'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --preheat 0 --steps 2 --warmup 1 --no-cpu-baseline (separate passes; tools/make_profiles.sh)',
-        'kernel': 'kvq_scan_seeded', 'reads_per_gpu': reads, 'launches_per_step': launches_per_step,
+        'kernel': kernel, 'reads_per_gpu': reads, 'launches_per_step': launches_per_step,
+        'source_sha256': bench.source_sha256(), 'git_head': head,
         'note': 'gfx950: FETCH_SIZE counts 1/2 of the bytes of a 16-B-per-lane streaming read (MI355X_MICROARCH.md, HBM section), '
                 'so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact. Per-launch values are the mean over the launches of the run. '
                 'The excess over the algorithmic bytes is the look-ahead every tile reads again (1040 bytes per 39760-byte tile for 150 bp records) plus seed-index and table lookups.',
