@@ -86,8 +86,7 @@ class Analyser(object):
         """applies ``.hits`` to fresh coverages (analyse.py:363-381)"""
         assert self.hits is not None and self.hitseqs is not None, 'cannot update coverages without .hits / .hitseqs'
         for c in self.coverages.values():
-            c.coverage = [0] * len(c.plus_seq)
-            c.mutations = {}
+            c.clear()
         n = len(self.coverages)
         for hit, hitseq in zip(self.hits, self.hitseqs):
             if isinstance(hitseq, bytes):
@@ -157,10 +156,12 @@ class Analyser(object):
 def json_dump(data, fd, indent=2, max_indent_level=2):
     """writes ``data`` as JSON with the first ``max_indent_level`` levels indented and everything
     below on one line (the layout of kvarq/util.py:272-294, so that a coverage string or a hit stays
-    on one line)"""
+    on one line).  Byte for byte what the reference writes: it runs Python 2.7's ``json.JSONEncoder(indent=2)``,
+    whose item separator stays ", " when it indents, so an indented line that is followed by another ends in
+    a comma AND a blank; below the indented levels the separators are ", " and ": " as well."""
     def emit(obj, level):
         if level >= max_indent_level or not isinstance(obj, (dict, list, tuple)) or not obj:
-            fd.write(json.dumps(obj))
+            fd.write(json.dumps(obj, separators=(', ', ': ')))
             return
         pad, pad_in = ' ' * (indent * level), ' ' * (indent * (level + 1))
         if isinstance(obj, dict):
@@ -168,13 +169,13 @@ def json_dump(data, fd, indent=2, max_indent_level=2):
             for i, (k, v) in enumerate(obj.items()):
                 fd.write(pad_in + json.dumps(str(k)) + ': ')
                 emit(v, level + 1)
-                fd.write(',\n' if i + 1 < len(obj) else '\n')
+                fd.write(', \n' if i + 1 < len(obj) else '\n')
             fd.write(pad + '}')
         else:
             fd.write('[\n')
             for i, v in enumerate(obj):
                 fd.write(pad_in)
                 emit(v, level + 1)
-                fd.write(',\n' if i + 1 < len(obj) else '\n')
+                fd.write(', \n' if i + 1 < len(obj) else '\n')
             fd.write(pad + ']')
     emit(data, 0)

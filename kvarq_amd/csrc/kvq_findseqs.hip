@@ -7,10 +7,14 @@
 #include "kvq_host.h"
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <string.h>
 #include <zlib.h>
 #include <thread>
+#include <sys/mman.h>
 #include <unistd.h>
 
 int64_t kvq_tail_record(const uint8_t *buf, int64_t n);
@@ -69,9 +73,234 @@ static void live_from_counters(const kvq_table *t, const int64_t *ctr, int64_t p
 // the inflated stream of a list of files
 // ---------------------------------------------------------------------------
 
+// Serial inflate of one .gz file, member after member (workhorse.c:482-541, 559-629, 790-884).  It owns its
+// FILE and knows nothing of the stream around it, so that it can run ahead of the stream in a thread of its
+// own (GzAhead): an error is kept -- code, message, position within the file's inflated bytes -- for the
+// stream's thread to raise.
+struct GzSerial {
+    FILE *fd = nullptr; z_stream zs; bool zs_live = false; uint8_t *inbuf = nullptr;
+    int64_t remaining = 0;      // compressed bytes of the file not yet read
+    int64_t consumed = 0;       // compressed bytes of the file behind the read position (what ftell() says)
+    int64_t produced = 0;       // inflated bytes handed out
+    int err = 0; char msg[256]; int64_t err_at = -1;          // err_at >= 0: the message ends " fpos=<stream offset of the file + err_at>"
+
+    ~GzSerial() { close(); free(inbuf); }
+    void close()
+    {
+        if (zs_live) { inflateEnd(&zs); zs_live = false; }
+        if (fd) { fclose(fd); fd = nullptr; }
+    }
+    int fail(int code, const char *fmt, const char *a = "", const char *b = "")
+    {
+        err = code; snprintf(msg, sizeof(msg), fmt, a, b); return code;
+    }
+    int getc_counted() { const int c = fgetc(fd); if (c != EOF) consumed++; return c; }
+
+    // workhorse.c:482-541
+    const char *skip_gz_header(int dist)
+    {
+        int state = 0, y = 0, c;
+        for (c = getc_counted(); state != 2 && y <= dist && c != EOF; c = getc_counted()) {
+            if (c == 0x1F && state == 0) state = 1;
+            else if (c == 0x8B && state == 1) state = 2;
+            else { state = 0; y++; }
+        }
+        if (state != 2) return "magic bytes not found";
+        if (c != 8) return "expected method==DEFLATED";
+        const int flags = getc_counted();
+        if (flags & (0x02 | 0x20 | 0xC0)) return "unsupported flags (CONTINUATION or ENCRYPTED or RESERVED)";
+        for (int i = 0; i < 6; i++) (void)getc_counted();
+        if (flags & 0x04) { int n = getc_counted(); n |= getc_counted() << 8; while (n-- > 0) (void)getc_counted(); }
+        if (flags & 0x08) { do c = getc_counted(); while (c > 0); }
+        if (flags & 0x10) { do c = getc_counted(); while (c > 0); }
+        return nullptr;
+    }
+
+    // takes over `f`, positioned at file offset `at` of `file_size`: at == 0 is the beginning of the file (the header
+    // must start right there, workhorse.c:613-621), anything else a later member (header within 10 bytes; *no_member
+    // when there is none: the stream ends, workhorse.c:851-853)
+    int start(FILE *f, int64_t file_size, int64_t at, bool *no_member)
+    {
+        fd = f; consumed = at; produced = 0; err = 0; err_at = -1;
+        if (no_member) *no_member = false;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -MAX_WBITS) != Z_OK) return fail(KVQ_ERR_RUNTIME, "cannot mz_inflateInit()");
+        zs_live = true;
+        if (!inbuf) inbuf = (uint8_t *)malloc(KVQ_SCANBUFSIZE);
+        if (!inbuf) return fail(KVQ_ERR_MEMORY, "cannot allocate inbuf");
+        fseek(fd, (long)at, SEEK_SET);
+        remaining = file_size - at;
+        const char *m = skip_gz_header(at == 0 ? 0 : 10);
+        if (m) {
+            if (at == 0) return fail(KVQ_ERR_IO, "no valid gzip header found at beginning of file : %s", m);
+            *no_member = true; return KVQ_OK;
+        }
+        remaining -= consumed - at;
+        return KVQ_OK;
+    }
+
+    // up to cap inflated bytes; *eof when the file is exhausted; -1 (and err/msg/err_at) on failure
+    int64_t read(uint8_t *dst, int64_t cap, bool *eof)
+    {
+        *eof = false;
+        zs.next_out = dst; zs.avail_out = (uInt)cap;
+        bool done = false;
+        while (zs.avail_out > 0 && !done) {
+            if (zs.avail_in == 0) {
+                if (remaining <= 0) { done = true; break; }
+                const int64_t m = std::min<int64_t>(KVQ_SCANBUFSIZE, remaining);
+                if ((int64_t)fread(inbuf, 1, (size_t)m, fd) != m) {
+                    fail(KVQ_ERR_IO, "could not read enough bytes from .fastq.gz%s%s", ferror(fd) ? " : I/O error" : "", feof(fd) ? " : premature EOF" : "");
+                    return -1;
+                }
+                consumed += m; remaining -= m;
+                zs.next_in = inbuf; zs.avail_in = (uInt)m;
+            }
+            const int st = inflate(&zs, Z_SYNC_FLUSH);
+            if (st != Z_OK && st != Z_STREAM_END && st != Z_BUF_ERROR) {
+                err = KVQ_ERR_IO; snprintf(msg, sizeof(msg), "error while inflating compressed data : status=%d", st);
+                err_at = produced + (cap - zs.avail_out);
+                return -1;
+            }
+            if (st == Z_STREAM_END) {
+                // another gzip member follows when more than a trailer is left (842-866)
+                if (remaining + (int64_t)zs.avail_in > 10) {
+                    fseek(fd, -(long)zs.avail_in, SEEK_CUR);
+                    consumed -= zs.avail_in; remaining += zs.avail_in; zs.avail_in = 0;
+                    const int64_t before = consumed;
+                    const char *m = skip_gz_header(10);
+                    if (m) { remaining = 0; done = true; }
+                    else {
+                        remaining -= consumed - before;
+                        uint8_t *no = zs.next_out; const uInt ao = zs.avail_out;
+                        inflateEnd(&zs); memset(&zs, 0, sizeof(zs)); inflateInit2(&zs, -MAX_WBITS);
+                        zs.next_out = no; zs.avail_out = ao;
+                    }
+                } else done = true;
+            } else if (st == Z_BUF_ERROR && zs.avail_in == 0 && remaining <= 0) done = true;
+        }
+        const int64_t n = cap - zs.avail_out;
+        if (zs.avail_out > 0) *eof = true;
+        produced += n;
+        return n;
+    }
+};
+
+// A GzSerial in a thread of its own, inflating into a queue of blocks for the stream to pick up.  The stream
+// is strictly one file after the other (the file positions of hits count inflated bytes of every file before,
+// workhorse.c:641-686), but nothing says the files must be INFLATED one after the other: the reader of the
+// second file of a pair starts together with the first file's and runs up to `budget` inflated bytes ahead.
+struct GzAhead {
+    struct Block { uint8_t *p; int64_t n, used, consumed_after; bool eof, failed; };
+    static const int64_t BLOCK = 4 << 20;
+    GzSerial z; int open_err = 0;
+    std::thread th; std::mutex m; std::condition_variable cv; std::deque<Block> q;
+    int64_t queued = 0, budget = 0; bool quit = false;
+    std::vector<uint8_t *> spare;                 // blocks handed back by the consumer, written again without page faults
+
+    // a fresh block costs a page fault per 4 KiB written, a third of the inflate time itself: ask for huge pages
+    static uint8_t *new_block()
+    {
+        void *p = nullptr;
+        if (posix_memalign(&p, 2 << 20, (size_t)BLOCK)) return nullptr;
+        (void)madvise(p, (size_t)BLOCK, MADV_HUGEPAGE);
+        return (uint8_t *)p;
+    }
+
+    GzAhead(const char *name, int64_t budget_bytes) : budget(budget_bytes)
+    {
+        FILE *f = fopen(name, "rb");
+        if (!f) { open_err = z.fail(KVQ_ERR_IO, "cannot open file"); return; }
+        fseek(f, 0, SEEK_END); const int64_t size = ftell(f);
+        open_err = z.start(f, size, 0, nullptr);
+        if (!open_err) th = std::thread([this] { run(); });
+    }
+    ~GzAhead()
+    {
+        { std::lock_guard<std::mutex> l(m); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+        for (auto &b : q) free(b.p);
+        for (auto p : spare) free(p);
+    }
+    void run()
+    {
+        for (;;) {
+            uint8_t *mem = nullptr;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return quit || queued < budget; });
+                if (quit) return;
+                if (!spare.empty()) { mem = spare.back(); spare.pop_back(); }
+            }
+            Block b = { mem ? mem : new_block(), 0, 0, 0, false, false };
+            if (!b.p) { z.fail(KVQ_ERR_MEMORY, "cannot allocate memory for scanning"); b.failed = true; }
+            else {
+                const int64_t n = z.read(b.p, BLOCK, &b.eof);
+                if (n < 0) b.failed = true; else b.n = n;
+            }
+            b.consumed_after = z.consumed;
+            const bool last = b.eof || b.failed;
+            {
+                std::lock_guard<std::mutex> l(m);
+                q.push_back(b); queued += b.n;
+            }
+            cv.notify_all();
+            if (last) return;
+        }
+    }
+    // the consumer's side of GzSerial::read; *consumed follows the compressed bytes behind what has been handed out.
+    // Whatever is queued is copied out by up to `nthreads` threads at once: behind the first file of a pair the whole
+    // second file may be waiting, and one memcpy stream would then be what the scan waits for.
+    int64_t read(uint8_t *dst, int64_t cap, bool *eof, int64_t *consumed, int nthreads)
+    {
+        struct Span { const uint8_t *from; uint8_t *to; int64_t n; };
+        *eof = false;
+        int64_t n = 0;
+        while (n < cap && !*eof) {
+            std::vector<Span> spans;
+            size_t whole = 0;                             // blocks used up by this round
+            bool failed = false;
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return !q.empty(); });
+                for (auto &b : q) {                       // (only this thread pops, and a deque keeps its elements in place when the reader pushes)
+                    const int64_t k = std::min(cap - n, b.n - b.used);
+                    if (k > 0) spans.push_back({ b.p + b.used, dst + n, k });
+                    n += k; b.used += k;
+                    if (b.used < b.n) break;              // cap reached inside the block
+                    *consumed = b.consumed_after;
+                    if (b.failed) { failed = true; break; }
+                    whole++;
+                    if (b.eof) { *eof = true; break; }
+                    if (n == cap) break;
+                }
+            }
+            int64_t bytes = 0;
+            for (auto &sp : spans) bytes += sp.n;
+            const int nt = bytes < (8 << 20) ? 1 : std::max(1, std::min<int>(std::min<int>(nthreads, 8), (int)spans.size()));
+            auto copy = [&](int t) { for (size_t i = (size_t)t; i < spans.size(); i += (size_t)nt) memcpy(spans[i].to, spans[i].from, (size_t)spans[i].n); };
+            std::vector<std::thread> helpers;
+            for (int t = 1; t < nt; t++) helpers.emplace_back(copy, t);
+            copy(0);
+            for (auto &h : helpers) h.join();
+            if (failed) return -1;
+            {
+                std::lock_guard<std::mutex> l(m);
+                for (; whole > 0; whole--) {
+                    if (spare.size() < 4) spare.push_back(q.front().p); else free(q.front().p);
+                    queued -= q.front().n; q.pop_front();
+                }
+            }
+            cv.notify_all();
+        }
+        return n;
+    }
+};
+
 class StreamSource {
 public:
-    ~StreamSource() { close_file(); free(inbuf_); }
+    ~StreamSource() { close_file(); }
 
     // workhorse.c:641-686: sizes of all files first, then the first file is opened
     int open(const char *const *files, int nfiles)
@@ -94,7 +323,7 @@ public:
         const std::string &name = files_[next_++];
         fd_ = fopen(name.c_str(), "rb");
         if (!fd_) { kvq_set_error(KVQ_ERR_IO, "cannot open file"); return KVQ_ERR_IO; }
-        consumed_ = 0; file_done_ = false;
+        consumed_ = 0; file_done_ = false; opened_ = true; file_fpos0_ = fpos_;
         fseek(fd_, 0, SEEK_END); file_size_ = ftell(fd_); fseek(fd_, 0, SEEK_SET);
         gz_ = name.size() >= 3 && name.compare(name.size() - 3, 3, ".gz") == 0;     // by suffix (582)
         bgzf_ = false;
@@ -104,18 +333,20 @@ public:
             // which also takes over should a later member not be a BGZF block
             BgzfBlock first;
             const char *sw = getenv("KVQ_BGZF");                              // KVQ_BGZF=0: serial reader only (diagnostic)
-            if (!(sw && sw[0] == '0') && bgzf_peek(0, &first)) { bgzf_ = true; boff_ = 0; total_ *= 3; return KVQ_OK; }
-            memset(&zs_, 0, sizeof(zs_));
-            if (inflateInit2(&zs_, -MAX_WBITS) != Z_OK) { kvq_set_error(KVQ_ERR_RUNTIME, "cannot mz_inflateInit()"); return KVQ_ERR_RUNTIME; }
-            zs_live_ = true;
-            if (!inbuf_) inbuf_ = (uint8_t *)malloc(KVQ_SCANBUFSIZE);
-            if (!inbuf_) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate inbuf"); return KVQ_ERR_MEMORY; }
-            fseek(fd_, 0, SEEK_END); remaining_ = ftell(fd_); fseek(fd_, 0, SEEK_SET);
-            const char *msg = skip_gz_header(0);
-            if (msg) { kvq_set_error(KVQ_ERR_IO, "no valid gzip header found at beginning of file : %s", msg); return KVQ_ERR_IO; }
-            remaining_ -= consumed_;
+            if (!(sw && sw[0] == '0') && bgzf_peek(0, &first)) { bgzf_ = true; boff_ = 0; total_ *= 3; start_next_ahead(); return KVQ_OK; }
+            if (ahead_next_ && ahead_next_for_ == next_ - 1) ahead_ = std::move(ahead_next_);     // its reader has been running since the file before was opened
+            else if (ahead_budget() > 0) ahead_.reset(new GzAhead(name.c_str(), ahead_budget()));
+            if (ahead_) {
+                if (ahead_->open_err) return raise(ahead_->z);
+            } else {
+                int rc = z_.start(fd_, file_size_, 0, nullptr);
+                fd_ = nullptr;                                                        // (z_ owns the FILE now)
+                if (rc) return raise(z_);
+                consumed_ = z_.consumed;
+            }
             total_ *= 3;                                                              // "random guess" (625)
         }
+        start_next_ahead();
         return KVQ_OK;
     }
 
@@ -158,43 +389,17 @@ public:
                 const int64_t got = read_bgzf(dst, cap, eof);
                 if (got != -2) return got;            // -2: the next member is no BGZF block -> serial path from here on
             }
-            zs_.next_out = dst; zs_.avail_out = (uInt)cap;
-            bool done = false;
-            while (zs_.avail_out > 0 && !done) {
-                if (zs_.avail_in == 0) {
-                    if (remaining_ <= 0) { done = true; break; }
-                    const int64_t m = std::min<int64_t>(KVQ_SCANBUFSIZE, remaining_);
-                    if ((int64_t)fread(inbuf_, 1, (size_t)m, fd_) != m) {
-                        kvq_set_error(KVQ_ERR_IO, "could not read enough bytes from .fastq.gz%s%s", ferror(fd_) ? " : I/O error" : "", feof(fd_) ? " : premature EOF" : "");
-                        return -1;
-                    }
-                    consumed_ += m; remaining_ -= m;
-                    zs_.next_in = inbuf_; zs_.avail_in = (uInt)m;
-                }
-                const int st = inflate(&zs_, Z_SYNC_FLUSH);
-                if (st != Z_OK && st != Z_STREAM_END && st != Z_BUF_ERROR) {
-                    kvq_set_error(KVQ_ERR_IO, "error while inflating compressed data : status=%d fpos=%ld", st, (long)(fpos_ + (cap - zs_.avail_out)));
-                    return -1;
-                }
-                if (st == Z_STREAM_END) {
-                    // another gzip member follows when more than a trailer is left (842-866)
-                    if (remaining_ + (int64_t)zs_.avail_in > 10) {
-                        fseek(fd_, -(long)zs_.avail_in, SEEK_CUR);
-                        consumed_ -= zs_.avail_in; remaining_ += zs_.avail_in; zs_.avail_in = 0;
-                        const int64_t before = consumed_;
-                        const char *msg = skip_gz_header(10);
-                        if (msg) { remaining_ = 0; done = true; }
-                        else {
-                            remaining_ -= consumed_ - before;
-                            uint8_t *no = zs_.next_out; const uInt ao = zs_.avail_out;
-                            inflateEnd(&zs_); memset(&zs_, 0, sizeof(zs_)); inflateInit2(&zs_, -MAX_WBITS);
-                            zs_.next_out = no; zs_.avail_out = ao;
-                        }
-                    } else done = true;
-                } else if (st == Z_BUF_ERROR && zs_.avail_in == 0 && remaining_ <= 0) done = true;
+            bool end = false;
+            if (ahead_) {
+                kvq_config cfg; kvq_config_get(&cfg);
+                n = ahead_->read(dst, cap, &end, &consumed_, cfg.nthreads);
+                if (n < 0) { raise(ahead_->z); return -1; }
+            } else {
+                n = z_.read(dst, cap, &end);
+                if (n < 0) { raise(z_); return -1; }
+                consumed_ = z_.consumed;
             }
-            n = cap - zs_.avail_out;
-            if (zs_.avail_out > 0) { *eof = true; file_done_ = true; }
+            if (end) { *eof = true; file_done_ = true; }
             // running estimate of the inflated size, float arithmetic as in 883-884
             if (ftell0_ + consumed_ > 0)
                 total_ = (int64_t)(size_t)((float)size_ * (fpos_ + n) / (ftell0_ + consumed_));
@@ -255,17 +460,14 @@ private:
         if (handover && blocks.empty()) {
             // the serial reader continues at this member: position the file, skip its header as open_next does
             bgzf_ = false;
-            memset(&zs_, 0, sizeof(zs_));
-            if (inflateInit2(&zs_, -MAX_WBITS) != Z_OK) { kvq_set_error(KVQ_ERR_RUNTIME, "cannot mz_inflateInit()"); return -1; }
-            zs_live_ = true;
-            if (!inbuf_) inbuf_ = (uint8_t *)malloc(KVQ_SCANBUFSIZE);
-            if (!inbuf_) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate inbuf"); return -1; }
-            fseek(fd_, (long)boff_, SEEK_SET);
-            remaining_ = file_size_ - boff_;
-            const int64_t before = consumed_;
-            const char *msg = skip_gz_header(10);
-            if (msg) { *eof = true; file_done_ = true; return 0; }          // as behind any member: no further header, the stream ends (851-853)
-            remaining_ -= consumed_ - before;
+            bool no_member = false;
+            z_.consumed = consumed_;
+            const int rc = z_.start(fd_, file_size_, boff_, &no_member);
+            fd_ = nullptr;
+            if (rc) { raise(z_); return -1; }
+            // (GzSerial counts file offsets; the stream's count of this file also holds what the block reader skipped)
+            consumed_ += z_.consumed - boff_; z_.consumed = consumed_;
+            if (no_member) { *eof = true; file_done_ = true; return 0; }          // as behind any member: no further header, the stream ends (851-853)
             return -2;
         }
         // read the compressed bytes of the whole run once, then inflate block by block in parallel
@@ -314,37 +516,59 @@ private:
         return out;
     }
 
-    int getc_counted() { const int c = fgetc(fd_); if (c != EOF) consumed_++; return c; }
-
-    // workhorse.c:482-541
-    const char *skip_gz_header(int dist)
+    // an error met by a gzip reader, possibly in its own thread, raised in this one
+    int raise(const GzSerial &z)
     {
-        int state = 0, y = 0, c;
-        for (c = getc_counted(); state != 2 && y <= dist && c != EOF; c = getc_counted()) {
-            if (c == 0x1F && state == 0) state = 1;
-            else if (c == 0x8B && state == 1) state = 2;
-            else { state = 0; y++; }
+        if (z.err_at >= 0) kvq_set_error(z.err, "%s fpos=%ld", z.msg, (long)(file_fpos0_ + z.err_at));
+        else kvq_set_error(z.err, "%s", z.msg);
+        return z.err;
+    }
+
+    // inflated bytes a reader may run ahead of the stream: KVQ_GZ_AHEAD_MB, else a quarter of the free memory up to
+    // 16 GiB; none with nthreads == 1 (one worker was asked for)
+    static int64_t ahead_budget()
+    {
+        kvq_config cfg; kvq_config_get(&cfg);
+        if (cfg.nthreads <= 1) return 0;
+        if (const char *e = getenv("KVQ_GZ_AHEAD_MB")) return (int64_t)atol(e) << 20;
+        const int64_t avail = (int64_t)sysconf(_SC_AVPHYS_PAGES) * sysconf(_SC_PAGESIZE);
+        return std::max<int64_t>(64ll << 20, std::min<int64_t>(avail / 4, 16ll << 30));
+    }
+
+    // the file after the one just opened: when it is a plain .gz (not BGZF -- those are inflated block-parallel when
+    // their turn comes), its reader starts now
+    void start_next_ahead()
+    {
+        if (next_ >= files_.size() || ahead_next_ || ahead_budget() <= 0) return;
+        const std::string &name = files_[next_];
+        if (!(name.size() >= 3 && name.compare(name.size() - 3, 3, ".gz") == 0)) return;
+        const char *sw = getenv("KVQ_BGZF");
+        if (!(sw && sw[0] == '0')) {
+            FILE *keep = fd_; const int64_t keep_size = file_size_;
+            FILE *f = fopen(name.c_str(), "rb");
+            if (!f) return;                                     // (open_next reports it when the file's turn comes)
+            fseek(f, 0, SEEK_END); file_size_ = ftell(f); fd_ = f;
+            BgzfBlock first;
+            const bool is_bgzf = bgzf_peek(0, &first);
+            fclose(f); fd_ = keep; file_size_ = keep_size;
+            if (is_bgzf) return;
         }
-        if (state != 2) return "magic bytes not found";
-        if (c != 8) return "expected method==DEFLATED";
-        const int flags = getc_counted();
-        if (flags & (0x02 | 0x20 | 0xC0)) return "unsupported flags (CONTINUATION or ENCRYPTED or RESERVED)";
-        for (int i = 0; i < 6; i++) (void)getc_counted();
-        if (flags & 0x04) { int n = getc_counted(); n |= getc_counted() << 8; while (n-- > 0) (void)getc_counted(); }
-        if (flags & 0x08) { do c = getc_counted(); while (c > 0); }
-        if (flags & 0x10) { do c = getc_counted(); while (c > 0); }
-        return nullptr;
+        ahead_next_.reset(new GzAhead(name.c_str(), ahead_budget()));
+        ahead_next_for_ = next_;
     }
 
     void close_file()
     {
-        if (fd_) { ftell0_ += consumed_; fclose(fd_); fd_ = nullptr; }
-        if (zs_live_) { inflateEnd(&zs_); zs_live_ = false; }
+        if (opened_) { ftell0_ += consumed_; opened_ = false; }
+        if (fd_) { fclose(fd_); fd_ = nullptr; }
+        z_.close(); ahead_.reset();
     }
 
     std::vector<std::string> files_; size_t next_ = 0;
     FILE *fd_ = nullptr; bool gz_ = false, file_done_ = true;
-    z_stream zs_; bool zs_live_ = false; uint8_t *inbuf_ = nullptr; int64_t remaining_ = 0;
+    bool opened_ = false; int64_t file_fpos0_ = 0;                              // a file is open / the stream offset it began at
+    GzSerial z_;                                                                // serial .gz reader in this thread ...
+    std::unique_ptr<GzAhead> ahead_, ahead_next_; size_t ahead_next_for_ = 0;   // ... or in its own; the next file's, already running
     bool bgzf_ = false; int64_t boff_ = 0; std::vector<uint8_t> cbuf_;       // BGZF: next block's file offset, compressed run
     int64_t size_ = 0, ftell0_ = 0, consumed_ = 0, fpos_ = 0, total_ = 0, file_size_ = 0;
 };
@@ -452,12 +676,12 @@ struct ScanSink {
 };
 
 // one pass over the files with the current arena; KVQ_NEED_RESCAN asks for another
-static int findseqs_pass(kvq_scan *s, const char *const *files, int nfiles, uint8_t *pin, int64_t pin_cap)
+static int findseqs_pass(kvq_scan *s, const char *const *files, int nfiles, uint8_t *pin, uint8_t *pin2, int64_t pin_cap)
 {
     ScanSink sink; sink.s = s;
     int64_t parsed = 0, total = 0;
     const double tp0 = now_ms();
-    int rc = stream_batches(sink, files, nfiles, pin, pin_cap, &parsed, &total, pin + pin_cap);     // two host buffers
+    int rc = stream_batches(sink, files, nfiles, pin, pin_cap, &parsed, &total, pin2);                 // two host buffers
     if (g_timing) fprintf(stderr, "findseqs pass: stream %.1f ms\n", now_ms() - tp0);
     if (rc) return rc;
     s->parsed = parsed; s->total = total;
@@ -518,10 +742,16 @@ extern "C" kvq_scan *kvq_findseqs(const char *const *files, int32_t nfiles,
         kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for scanning"); g_pin = nullptr;
     }
     uint8_t *const pin = g_pin;
+    // KVQ_BATCH_MB=<2..64>: smaller batches (diagnostic: many batches out of a small file); the buffers keep their size
+    int64_t use_cap = pin_cap;
+    if (const char *mb = getenv("KVQ_BATCH_MB")) {
+        const long v = atol(mb);
+        if (v >= 2 && (v << 20) < BATCH_BYTES) use_cap = ((int64_t)v << 20) + 2 * KVQ_SCANBUFSIZE;
+    }
     const double tf2 = now_ms();
     if (s && pin) {
         for (int attempt = 0; attempt < 4; attempt++) {
-            const int rc = findseqs_pass(s, files, nfiles, pin, pin_cap);
+            const int rc = findseqs_pass(s, files, nfiles, pin, pin + pin_cap, use_cap);
             if (rc != KVQ_NEED_RESCAN) break;
             // the hit arena was too small (it has been enlarged): scan again from the start
             if (kvq_scan_reset(s)) break;

@@ -135,8 +135,8 @@ def test_json_dump_layout_and_round_trip():
     text = out.getvalue()
     assert json.loads(text) == json.loads(json.dumps(data))
     lines = text.split('\n')
-    assert '  "coverages": [' in lines and '    ["SNP1", "1-2-3 1[T]"],' in lines          # third level on one line
-    assert '    "fastq": ["a_1.fastq", "a_2.fastq"],' in lines and '    "readlengths": [0, 1, 2],' in lines
+    assert '  "coverages": [' in lines and '    ["SNP1", "1-2-3 1[T]"], ' in lines         # third level on one line (", " ends the line: Python 2.7's separator)
+    assert '    "fastq": ["a_1.fastq", "a_2.fastq"], ' in lines and '    "readlengths": [0, 1, 2], ' in lines
     assert lines[0] == '{' and lines[-1] == '}'
 
 
@@ -184,3 +184,50 @@ def test_analyser_scan_encode_decode(tmp_path):
     dev = coverages_from_scan(plus, r, t)
     assert [c.serialize() for c in dev] == [c.serialize() for c in a.coverages.values()]
     s.close(); t.close()
+
+
+def test_json_dump_layout_is_the_references_byte_for_byte():
+    """kvarq/util.py:272-294 writes an analysis as JSON with two levels indented (two blanks each) and everything
+    below on one line.  The expected text is derived by hand from that rule: the reference feeds the chunks of
+    Python 2.7's ``json.JSONEncoder(indent=2)`` -- whose item separator is ", " also when it indents, so that a
+    line which is followed by another item ends in ", " -- through two regular expressions: one strips the line
+    breaks and indentation of more than four blanks (levels three and deeper collapse onto their parent's line:
+    `"fastq": ["a_1.fastq", "a_2.fastq"]`), the other holds back the line break in front of a bracket that closes
+    such a collapsed level.  Empty containers stay `[]`; the top level closes on a line of its own."""
+    import collections
+    import io
+    from kvarq_amd.analyse import json_dump
+    data = collections.OrderedDict([
+        ('analyses', collections.OrderedDict([('MTBC/spoligo', ['SIT 53', 'octal 777777777760771'])])),
+        ('info', collections.OrderedDict([('fastq', ['a_1.fastq', 'a_2.fastq']), ('scantime', 1.5),
+                                          ('config', collections.OrderedDict([('maxerrors', 2), ('Amin', '.')]))])),
+        ('coverages', [['spacer1', '2-2-2 1[T]'], ['spacer2', '0-0-0 ']]),
+        ('hits', [[0, 54, -12, 3, 51]]),
+        ('empty', []),
+        ('n', 3),
+    ])
+    expected = (
+        '{\n'
+        '  "analyses": {\n'
+        '    "MTBC/spoligo": ["SIT 53", "octal 777777777760771"]\n'
+        '  }, \n'
+        '  "info": {\n'
+        '    "fastq": ["a_1.fastq", "a_2.fastq"], \n'
+        '    "scantime": 1.5, \n'
+        '    "config": {"maxerrors": 2, "Amin": "."}\n'
+        '  }, \n'
+        '  "coverages": [\n'
+        '    ["spacer1", "2-2-2 1[T]"], \n'
+        '    ["spacer2", "0-0-0 "]\n'
+        '  ], \n'
+        '  "hits": [\n'
+        '    [0, 54, -12, 3, 51]\n'
+        '  ], \n'
+        '  "empty": [], \n'
+        '  "n": 3\n'
+        '}')
+    fd = io.StringIO()
+    json_dump(data, fd)
+    assert fd.getvalue() == expected
+    import json
+    assert json.loads(fd.getvalue(), object_pairs_hook=collections.OrderedDict) == json.loads(json.dumps(data), object_pairs_hook=collections.OrderedDict)

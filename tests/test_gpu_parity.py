@@ -287,28 +287,84 @@ def test_a_few_dozen_hits_per_read_are_ranked_by_the_wave(k):
     s.close(); t.close(); d.free()
 
 
-def test_concurrent_findseqs_is_refused_and_stop_works(tmp_path):
-    import threading, time
+def _wait_until_scanning(th, total, seconds=60):
+    """blocks until the scan (of ``total`` stream bytes) running in ``th`` has published the counters of a batch"""
+    import time
+    t0 = time.time()
+    while th.is_alive() and time.time() - t0 < seconds:
+        st = engine.stats()
+        if st['total'] == total and st['records_parsed'] > 0:      # (before it opens its files the last scan's state shows)
+            return True
+        time.sleep(0.0005)
+    return False
+
+
+def test_concurrent_findseqs_is_refused_and_stop_works(tmp_path, monkeypatch):
+    """a second findseqs while one runs raises (workhorse.c:1258-1262); stop() ends the running one at the next
+    batch with the hits found so far and no error (workhorse.c:1469-1479) -- BOTH must be seen"""
+    import threading
+    monkeypatch.setenv('KVQ_BATCH_MB', '2')                   # ~80 batches out of 156 MB: the scan cannot be over after two
     p = tmp_path / 'big.fastq'
     p.write_bytes(cases.multichunk() * 40)
+    total_records, total_bytes = 9000 * 40, 40 * len(cases.multichunk())
+    engine.config(**dict(cases.PRODUCT, nthreads=1))
+    out = {}
+
+    def run():
+        try:
+            out['r'] = engine.findseqs(str(p), cases.MULTI_SEQS)
+        except Exception as e:                                 # (would mean the main thread's call won the race)
+            out['e'] = e
+    th = threading.Thread(target=run)
+    th.start()
+    seen = _wait_until_scanning(th, total_bytes)
+    assert seen, 'the scan never published a batch: %r %r' % (out.get('e'), engine.stats())
+    with pytest.raises(RuntimeError, match='already running'):
+        engine.findseqs(str(p), cases.MULTI_SEQS)
+    engine.stop()
+    th.join()
+    assert 'e' not in out, out.get('e')
+    r = out['r']
+    st = r['stats']
+    assert 0 < st['records_parsed'] < total_records          # partial, and not empty
+    assert 0 < st['parsed'] < st['total'] == total_bytes
+    assert sum(st['readlengths']) == st['records_parsed']
+    assert len(r['hits']) == len(r['hitseqs']) == sum(st['nseqhits']) > 0
+    # what it did return is a prefix of the full scan: the hits of the records before the stop, in file order
+    full = engine.findseqs(str(p), cases.MULTI_SEQS)
+    assert full['stats']['records_parsed'] == total_records
+    assert tuple(full['hits'][:len(r['hits'])]) == tuple(r['hits'])
+    assert full['hitseqs'][:len(r['hits'])] == r['hitseqs']
+
+
+def test_stats_polled_from_another_thread_grow_monotonically(tmp_path, monkeypatch):
+    """engine.stats() during a scan of many batches (workhorse.c:1205-1244 reads the worker's counters while it
+    runs): every field only ever grows, it ends on the scan's own stats, and more than two distinct states are seen"""
+    import threading, time
+    monkeypatch.setenv('KVQ_BATCH_MB', '2')
+    p = tmp_path / 'big.fastq'
+    p.write_bytes(cases.multichunk() * 30)
     engine.config(**dict(cases.PRODUCT, nthreads=1))
     out = {}
     th = threading.Thread(target=lambda: out.setdefault('r', engine.findseqs(str(p), cases.MULTI_SEQS)))
+    seen = []
     th.start()
-    refused = False
-    for _ in range(2000):
-        if not th.is_alive():
-            break
-        try:
-            engine.findseqs(str(p), cases.MULTI_SEQS)
-        except RuntimeError as e:
-            refused = 'already running' in str(e)            # workhorse.c:1258-1262
-            engine.stop()                                     # workhorse.c:1469-1479: partial result, no error
-            break
-        time.sleep(0.001)
+    while th.is_alive():
+        seen.append(engine.stats())
+        time.sleep(0.0005)
     th.join()
-    assert 'r' in out and out['r']['stats']['records_parsed'] <= 9000 * 40
-    assert refused or out['r']['stats']['records_parsed'] == 9000 * 40
+    seen.append(engine.stats())
+    final = out['r']['stats']
+    assert seen[-1] == final
+    assert final['records_parsed'] == 9000 * 30 and final['progress'] == 1.0
+    started = [s for s in seen if s['total'] == final['total']]       # (polls before the scan opened its files see the last scan's state)
+    for a, b in zip(started, started[1:]):
+        assert a['records_parsed'] <= b['records_parsed']
+        assert a['parsed'] <= b['parsed'] and a['progress'] <= b['progress']
+        assert all(x <= y for x, y in zip(a['nseqhits'], b['nseqhits']))
+        assert all(x <= y for x, y in zip(a['nseqbasehits'], b['nseqbasehits']))
+        assert sum(a['readlengths']) == a['records_parsed']              # one consistent snapshot, not a torn one
+    assert len(set(s['records_parsed'] for s in started)) > 3
 
 
 def test_seeded_and_exhaustive_kernels_agree_and_paths_are_as_expected(tmp_path):

@@ -230,3 +230,46 @@ def test_bgzf_blocks_are_inflated_in_parallel_to_the_same_stream(tmp_path, nthre
     assert serial == (got, (parsed, total))
     got, (parsed, total) = plan([p1], 1 << 20)
     assert got == expected_plan([big]) and parsed == len(big)
+
+
+@pytest.mark.parametrize('ahead_mb', [None, '4', '0'])
+def test_the_second_gz_of_a_pair_is_inflated_ahead_to_the_same_stream(tmp_path, ahead_mb, monkeypatch):
+    """plain .gz files are inflated by a reader thread each, the next file's running ahead of the stream
+    (bounded by KVQ_GZ_AHEAD_MB): chunks, parsed bytes and the final size estimate == the one-thread reader's,
+    which the reference's own .gz outcomes pin (test_reader_stats_match_the_reference_on_gz)"""
+    a = cases.multichunk() * 3                      # 11.7 MB: several 4 MiB blocks queue up
+    b = cases.ragged(34, 30000, cases.RAGGED_TARGETS)
+    c = b'@tail\nACGT'
+    p = [str(tmp_path / n) for n in ('r_1.fastq.gz', 'r_2.fastq.gz', 'r_3.fastq.gz', 'r_4.fastq')]
+    open(p[0], 'wb').write(gzip.compress(a, 1, mtime=0))
+    with open(p[1], 'wb') as f:                      # two members
+        f.write(gzip.compress(b[:len(b) // 3], 1, mtime=0) + gzip.compress(b[len(b) // 3:], 1, mtime=0))
+    open(p[2], 'wb').write(gzip.compress(c, mtime=0) + b'\0\0\0\0')
+    open(p[3], 'wb').write(b)
+    saved = engine.get_config()
+    try:
+        engine.config(nthreads=1)
+        serial = plan(p, 3 << 20)
+        if ahead_mb is not None:
+            monkeypatch.setenv('KVQ_GZ_AHEAD_MB', ahead_mb)
+        engine.config(nthreads=4)
+        ahead = plan(p, 3 << 20)
+        # a damaged second file: the error is raised when the stream gets there, with the stream position
+        z = bytearray(open(p[1], 'rb').read())
+        z[len(gzip.compress(b[:len(b) // 3], 1, mtime=0)) + 10] = 0x07           # the second member opens with block type 3: invalid
+        open(p[1], 'wb').write(bytes(z))
+        bad_ahead = plan(p[:2], 3 << 20)
+        engine.config(nthreads=1)
+        bad_serial = plan(p[:2], 3 << 20)
+        nothing = str(tmp_path / 'x.fastq.gz')
+        open(nothing, 'wb').write(b'no gzip')
+        engine.config(nthreads=4)
+        bad_header = plan([p[0], nothing])
+    finally:
+        engine.config(**saved)
+    assert serial[0] == expected_plan([a, b, c, b]) and serial[1][0] == len(a) + 2 * len(b) + len(c)
+    assert ahead == serial
+    assert bad_serial[0] is None and bad_serial[1][0] == _lib.ERR_IO and 'error while inflating compressed data' in bad_serial[1][1]
+    assert bad_serial[1][1].endswith('fpos=%d' % (len(a) + len(b) // 3))
+    assert bad_ahead == bad_serial                                               # same status, same fpos
+    assert bad_header[0] is None and 'no valid gzip header found at beginning of file' in bad_header[1][1]

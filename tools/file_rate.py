@@ -51,4 +51,20 @@ for nt in (1, 4, 16):
         r = engine.findseqs(bpath, seqs)
         dt = time.perf_counter() - t0
     print('bgzf   nthreads=%2d  %.3f s  %.1f M reads/s  %.2f GB/s inflated  hits=%d' % (nt, dt, nb / dt / 1e6, nb * rb / dt / 1e9, len(r['hits'])))
-os.remove(path); os.remove(gzpath); os.remove(bpath)
+# a pair of ordinary .gz files (reads_1 / reads_2): the second file's reader runs ahead of the stream
+npair = 600_000
+pp = ['/tmp/kvq_rate_1.fastq.gz', '/tmp/kvq_rate_2.fastq.gz']
+for k, q in enumerate(pp):
+    with open(q, 'wb') as f:
+        f.write(gzip.compress(data[k * npair * rb:(k + 1) * npair * rb].tobytes(), 1))
+outs = []
+for nt, what in ((1, 'one reader, file after file'), (4, 'a reader per file')):
+    engine.config(maxerrors=2, minoverlap=25, minreadlength=25, Amin='.', nthreads=nt)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        r = engine.findseqs(pp, seqs)
+        dt = time.perf_counter() - t0
+    outs.append((r['hits'], r['hitseqs'], r['stats']))
+    print('gz pair nthreads=%2d  %.3f s  %.2f M reads/s  %.2f GB/s inflated (%s)  hits=%d' % (nt, dt, 2 * npair / dt / 1e6, 2 * npair * rb / dt / 1e9, what, len(r['hits'])))
+assert outs[0] == outs[1]
+os.remove(path); os.remove(gzpath); os.remove(bpath); os.remove(pp[0]); os.remove(pp[1])
