@@ -244,6 +244,10 @@ void kvq_poll_stats(kvq_live_stats *out, int64_t *readlengths /*[1024]*/,
                     int64_t *nseqhits, int64_t *nseqbasehits, int32_t nseq_cap);
 void kvq_request_stop(void);
 void kvq_count_sigint(void);    /* sigint_cb, workhorse.c:133-136 */
+/* signal(SIGINT, sigint_cb) of the module init (workhorse.c:1632) as an explicit, reversible call: a C handler
+ * that only counts, so that SIGINTs are counted while the calling thread is inside kvq_findseqs */
+int  kvq_sigint_counter_install(void);
+void kvq_sigint_counter_remove(void);
 
 /* ---- device + synthetic workload (bench / tests plumbing) -------------------- */
 int32_t kvq_device_count(void);

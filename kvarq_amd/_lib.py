@@ -84,6 +84,8 @@ PROTOTYPES = {
     'kvq_poll_stats': (None, [P(LiveStats), P(i64), P(i64), P(i64), i32]),
     'kvq_request_stop': (None, []),
     'kvq_count_sigint': (None, []),
+    'kvq_sigint_counter_install': (C.c_int, []),
+    'kvq_sigint_counter_remove': (None, []),
     'kvq_device_count': (i32, []),
     'kvq_set_device': (i32, [i32]),
     'kvq_device_alloc': (vp, [i64]),

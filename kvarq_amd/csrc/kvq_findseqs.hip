@@ -11,6 +11,7 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <signal.h>
 #include <string.h>
 #include <zlib.h>
 #include <thread>
@@ -34,6 +35,32 @@ static struct {
 
 extern "C" void kvq_request_stop(void) { g_stop++; }
 extern "C" void kvq_count_sigint(void) { g_sigints++; }
+
+// The reference installs its counting handler with signal() when the module is imported (workhorse.c:133-136,
+// 1632): a C handler, so that a SIGINT is counted while the main thread sits inside findseqs (a Python-level
+// handler only runs once the interpreter gets control back).  Here installing it is an explicit call, and it
+// can be undone; a lock-free atomic increment is all the handler does.
+static struct sigaction g_sigint_before;
+static bool g_sigint_installed = false;
+static void on_sigint(int) { g_sigints++; }
+static_assert(std::atomic<int>::is_always_lock_free, "the SIGINT handler only touches a lock-free counter");
+
+extern "C" int kvq_sigint_counter_install(void)
+{
+    if (g_sigint_installed) return KVQ_OK;
+    struct sigaction sa; memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = on_sigint; sigemptyset(&sa.sa_mask); sa.sa_flags = SA_RESTART;
+    if (sigaction(SIGINT, &sa, &g_sigint_before) != 0) { kvq_set_error(KVQ_ERR_RUNTIME, "cannot install the SIGINT handler"); return KVQ_ERR_RUNTIME; }
+    g_sigint_installed = true;
+    return KVQ_OK;
+}
+
+extern "C" void kvq_sigint_counter_remove(void)
+{
+    if (!g_sigint_installed) return;
+    (void)sigaction(SIGINT, &g_sigint_before, nullptr);
+    g_sigint_installed = false;
+}
 
 extern "C" void kvq_poll_stats(kvq_live_stats *out, int64_t *readlengths, int64_t *nseqhits, int64_t *nseqbasehits, int32_t nseq_cap)
 {

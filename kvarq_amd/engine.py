@@ -14,8 +14,6 @@ The scan itself runs only on the GPU: without the library or without a device
 """
 import collections
 import ctypes as C
-import signal
-import threading
 
 from . import _lib
 from .fastq import FastqFileFormatException
@@ -207,11 +205,16 @@ def test():
 
 
 def install_sigint_counter():
-    """the reference installs, at import, a SIGINT handler that only counts
+    """the reference installs, at import, a C SIGINT handler that only counts
     (workhorse.c:133-136, 1632; the CLI turns two of them into stop(), cli.py:156-164).
-    Replacing Python's handler is a process-wide side effect, so here it is an
-    explicit call: the ``kvarq/engine.py`` shim of INTEGRATION.md makes it."""
-    def _cb(signum, frame):
-        _lib.lib().kvq_count_sigint()
-    if threading.current_thread() is threading.main_thread():
-        signal.signal(signal.SIGINT, _cb)
+    Replacing the process's handler is a process-wide side effect, so here it is an
+    explicit call: the ``kvarq/engine.py`` shim of INTEGRATION.md makes it.  The handler
+    lives in the library (``kvq_sigint_counter_install``): it counts while the main
+    thread is inside ``findseqs``, where a Python-level handler would have to wait."""
+    if _lib.lib().kvq_sigint_counter_install():
+        _raise_last()
+
+
+def remove_sigint_counter():
+    """puts back the handler that was there before ``install_sigint_counter``"""
+    _lib.lib().kvq_sigint_counter_remove()

@@ -273,3 +273,20 @@ def test_the_second_gz_of_a_pair_is_inflated_ahead_to_the_same_stream(tmp_path, 
     assert bad_serial[1][1].endswith('fpos=%d' % (len(a) + len(b) // 3))
     assert bad_ahead == bad_serial                                               # same status, same fpos
     assert bad_header[0] is None and 'no valid gzip header found at beginning of file' in bad_header[1][1]
+
+
+def test_sigint_is_counted_by_a_c_handler_and_the_old_handler_comes_back():
+    """workhorse.c:133-136, 1632: SIGINT only counts (stats()['sigints']); findseqs zeroes the count (1264-1265)"""
+    import signal, time
+    engine.install_sigint_counter()
+    try:
+        n0 = engine.stats()['sigints']
+        os.kill(os.getpid(), signal.SIGINT)              # would raise KeyboardInterrupt under Python's own handler
+        os.kill(os.getpid(), signal.SIGINT)
+        time.sleep(0.05)
+        assert engine.stats()['sigints'] == n0 + 2
+    finally:
+        engine.remove_sigint_counter()
+    with pytest.raises(KeyboardInterrupt):               # Python's handler is back
+        os.kill(os.getpid(), signal.SIGINT)
+        time.sleep(1)
