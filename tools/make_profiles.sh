@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the measurement artifacts under profiles/ on an MI355X box (run through gpurun from the
-# repo root: `gpurun --timeout 1200 -- 'bash tools/make_profiles.sh round1'`).  Everything is written
+# repo root: `gpurun --timeout 1200 -- 'bash tools/make_profiles.sh round2'`).  Everything is written
 # under gpurun_out/<tag>/ ; copy what is to be kept into profiles/ afterwards (the script prints the cp lines).
 # PMC passes are separate runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-round1}
+TAG=${1:-round2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -43,8 +43,13 @@ print('%-44s step %.3f ms  kernel %.3f ms/launch (%d launch/step, %.3f GB)  roof
     sys.argv[1], d['ms_per_step'], r['avg_launch_ms'], r['launches_per_step'], r['algorithmic_bytes_per_launch'] / 1e9, r['frac'], d['value'] / 1e9))
 PY
 done
+step filerate; timeout -k 10 200 python3 tools/file_rate.py > $O/file_rate.txt 2>&1
+step clock; bash tools/clock_pmc.sh $TAG/clk > $O/clock.txt 2>&1
+step ubench
+( cd tools/ubench && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o valu_rate valu_rate.hip 2>/dev/null && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o issue_rate issue_rate.hip 2>/dev/null
+  timeout -k 10 120 ./valu_rate > $O/valu_rate.txt 2>&1 && timeout -k 10 120 ./issue_rate > $O/issue_rate.txt 2>&1 )
 step done
-for f in bench_n1.json rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt; do
+for f in bench_n1.json rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt clock.txt valu_rate.txt issue_rate.txt; do
   echo "cp gpurun_out/$TAG/$f profiles/${TAG}_$f"
 done
 cat $O/bench_n1.json
