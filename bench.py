@@ -70,6 +70,9 @@ def main():
     ap.add_argument('--table', default='MTBC', choices=['MTBC', 'MTBC+barcodes'])
     ap.add_argument('--table-scale', type=int, default=1)
     ap.add_argument('--exhaustive', action='store_true', help='force the exhaustive kernel for every sequence')
+    ap.add_argument('--pipeline', type=int, default=3,
+                    help='scans in flight: step k+1 is enqueued (on its own scan object and stream) before the results of step k '
+                         'are waited for, so the GPU goes from one scan kernel to the next while the host collects a step (1: strictly one after the other)')
     ap.add_argument('--batch-bytes', type=int, default=(1 << 32) - (1 << 20), help='largest batch handed to kvq_scan_device')
     ap.add_argument('--preheat', type=int, default=30, help='untimed scans before the warmup steps (the GPU clocks take ~10 steps = 20 ms to settle in a fresh process)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -141,37 +144,71 @@ def main():
         batches.append((base, int(offs[j]) - base, (offs[i:j + 1] - base).copy()))
 
     table = scan.Table(seqs, **cfg)
-    ctr = None
+    depth = max(1, args.pipeline)
+    ctrs = None
     reduce_by = None
+    scanners = []
     if world > 1:
         # the join of the ranks: libkvarq_hip.so's own RCCL communicator (include/kvarq_hip.h, "several GPUs") --
-        # `finish` then sums the counter arrays of all ranks with one all-reduce on the scan's stream.  Should the
-        # library fail to make its communicator, the same sum is taken by torch.distributed (also RCCL) and the
-        # JSON line says so.
+        # `finish` then sums the counter arrays of all ranks with one all-reduce on the scan's stream.  Every scan in
+        # flight has a communicator of its own (collectives of one communicator must not overlap).  Should the
+        # library fail to make its communicators, the same sum is taken by torch.distributed (also RCCL), one scan
+        # at a time, and the JSON line says so.
         try:
-            comm = kdist.NativeComm.from_torch(dist, device='cuda' if backend == 'nccl' else None)
-            scanner = scan.Scanner(table)
-            scanner.set_comm(comm)
+            for _ in range(depth):
+                comm = kdist.NativeComm.from_torch(dist, device='cuda' if backend == 'nccl' else None)
+                sc = scan.Scanner(table)
+                sc.set_comm(comm)
+                scanners.append(sc)
             reduce_by = 'libkvarq_hip (RCCL all-reduce inside kvq_scan_finish)'
         except Exception as e:                       # noqa: BLE001
             sys.stderr.write('bench.py: native communicator unavailable (%s): reducing with torch.distributed\n' % e)
-            ctr = torch.zeros(table.counters_len, dtype=torch.int64, device='cuda')
-            scanner = scan.Scanner(table, ctr.data_ptr())
+            depth = 1
+            ctrs = [torch.zeros(table.counters_len, dtype=torch.int64, device='cuda')]
+            scanners = [scan.Scanner(table, ctrs[0].data_ptr())]
             reduce_by = 'torch.distributed all_reduce (RCCL)'
     else:
-        scanner = scan.Scanner(table)
+        scanners = [scan.Scanner(table) for _ in range(depth)]
     if args.exhaustive:
-        scanner.force_exhaustive(True)
+        for sc in scanners:
+            sc.force_exhaustive(True)
+    ctr = ctrs[0] if ctrs else None
 
-    def step():
-        scanner.reset()
+    # One step = reset + scan of the whole resident text + finish (ordered hits, hit bytes and summed counters on the
+    # host).  Steps are independent jobs; `depth` of them are in flight: a step's scan is enqueued, then the step that
+    # was enqueued depth - 1 calls earlier is finished.  Every step is finished inside the timed region.
+    in_flight = []
+
+    def begin(k):
+        sc = scanners[k % depth]
+        sc.reset()
         for base, nbytes, co in batches:
-            scanner.scan_device(d_data.ptr + base, nbytes, co, fpos_base=fpos0 + base)
-        r = scanner.finish(hits=False, stats=False)     # hits, hit bytes and counters are on the host (C arrays); no Python tuples or dicts here
+            sc.scan_device(d_data.ptr + base, nbytes, co, fpos_base=fpos0 + base)
+        in_flight.append(sc)
+
+    def end():
+        sc = in_flight.pop(0)
+        r = sc.finish(hits=False, stats=False)          # hits, hit bytes and counters are on the host (C arrays); no Python tuples or dicts here
         if ctr is not None:
             kdist.reduce_counters(ctr, dist)                            # hit/coverage arrays over xGMI (one sum all-reduce)
             torch.cuda.current_stream().synchronize()                   # the next step zeroes ctr on the scan's own stream
+        # every step is checked, not only the last one (the counters are a view of the scan's host array: read them now)
+        want = n * (world if ctr is None else 1)
+        got = int(r['counters'][_lib.CTR_RECORDS])
+        assert got == want, 'records lost: %d of %d' % (got, want)
+        r['records'] = got
         return r
+
+    def run(nsteps):
+        """nsteps whole steps; -> their results"""
+        out_ = []
+        for k in range(nsteps):
+            begin(k)
+            if len(in_flight) == depth:
+                out_.append(end())
+        while in_flight:
+            out_.append(end())
+        return out_
 
     def sync():
         L_.kvq_device_synchronize()
@@ -180,20 +217,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    r = None
-    for _ in range(max(0, args.preheat)):        # part of the setup: brings the clocks up, not counted as steps
-        r = step()
-    for _ in range(args.warmup):
-        r = step()
+    run(max(0, args.preheat))                    # part of the setup: brings the clocks up, not counted as steps
+    run(args.warmup)
     sync()
     t0 = time.perf_counter()
     kern_ms = main_ms = 0.0
     launches = 0
-    for _ in range(args.steps):
-        r = step()
-        kern_ms += r['kernel_ms']
-        main_ms += r['main_kernel_ms']
-        launches += r['main_kernel_launches']
+    results = run(args.steps)
+    r = results[-1]
+    assert len(results) == args.steps and len(set((x['records'], x['n_hits']) for x in results)) == 1, 'steps disagree'
+    for x in results:
+        kern_ms += x['kernel_ms']
+        main_ms += x['main_kernel_ms']
+        launches += x['main_kernel_launches']
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -235,13 +271,15 @@ def main():
                    'kernel_path': 'exhaustive' if args.exhaustive or not any(table.seeded) else
                                   'seed-filter k=%d (%d of %d sequences)' % (table.seed_k, sum(table.seeded), table.nseq),
                    'hits_per_step': total_hits, 'records_per_step': total_records,
-                   'preheat_steps': max(0, args.preheat)},
+                   'preheat_steps': max(0, args.preheat), 'steps_in_flight': depth},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                      'kernel': ('kvq_scan_seeded' if os.environ.get('KVQ_KERNEL') == 'v1' else 'kvq_scan_bp') if any(table.seeded) and not args.exhaustive else 'kvq_match_all',
                      'launches_per_step': launches // max(1, args.steps), 'avg_launch_ms': main_avg_ms,
                      'algorithmic_bytes_per_launch': bytes_per_launch,
-                     'all_kernels_ms_per_step': kern_ms / args.steps},
+                     # (HIP events around everything a step enqueues; with several steps in flight that span also holds the
+                     # wait for the scan kernel in front, so it is only quoted for --pipeline 1)
+                     'all_kernels_ms_per_step': kern_ms / args.steps if depth == 1 else None},
     }
     # HBM bytes per launch of the dominant kernel from the PMC passes of this same command
     # (profiles/, collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes)

@@ -869,7 +869,13 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     if (nt == 0) return KVQ_OK;
     // workgroups per launch: what the CUs hold at once (kvq_scan_bp four per CU, kvq_scan_seeded two)
     static const uint32_t grid_env = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 0);
-    const uint32_t grid_cap = grid_env ? grid_env : ix->variant ? 512u : 1024u;
+    // (a process that keeps several scan objects is taken to overlap their work -- the next job's scan with the
+    // last one's fold, ordering and copy: one CU in eight then keeps a workgroup slot free, so that those small
+    // kernels run beside the persistent workgroups of the scan instead of behind them; tools: bench.py --pipeline)
+    static const uint32_t cus = kvq_device_cu_count();
+    const uint32_t per_cu = ix->variant ? 2u : 4u;
+    const uint32_t grid_full = cus * per_cu, grid_shared = grid_full - cus / 8u;
+    const uint32_t grid_cap = grid_env ? grid_env : (!ix->variant && kvq_live_scans() > 1) ? grid_shared : grid_full;
     if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 24576 + KVQ_SKIP_CAP * 8 > s->pool.cap) {       // run_batch made the room
         kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;
     }

@@ -72,6 +72,8 @@ struct Batch {
 };
 
 struct kvq_comm;
+int kvq_live_scans();                 // scan objects alive in this process
+uint32_t kvq_device_cu_count();       // compute units of the current device
 int kvq_comm_reduce_counters(kvq_comm *c, unsigned long long *d_ctr, int64_t ctr_len, unsigned long long *d_scratch, hipStream_t stream);
 
 struct kvq_scan {

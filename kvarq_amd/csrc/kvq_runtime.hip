@@ -264,10 +264,20 @@ static int ensure_arena(kvq_scan *s, uint64_t hits, uint64_t blob)
     return KVQ_OK;
 }
 
+static std::atomic<int> g_live_scans{0};
+int kvq_live_scans() { return g_live_scans.load(); }
+uint32_t kvq_device_cu_count()
+{
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0) return 256u;
+    return (uint32_t)pr.multiProcessorCount;
+}
+
 extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
 {
     kvq_clear_error();
     kvq_scan *s = new kvq_scan();
+    g_live_scans++;
     s->t = t;
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         kvq_set_error(KVQ_ERR_DEVICE, "hipStreamCreate failed"); delete s; return nullptr;
@@ -300,11 +310,38 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     return s;
 }
 
+// The scan kernel is persistent and takes every wave slot and all of the LDS of every CU: two of them at once
+// (scan objects on different streams, e.g. a caller that enqueues the next job while it collects the last one)
+// only get in each other's way.  So the main kernels of a process form a chain: each waits for the one enqueued
+// before it, whatever stream that was on.  Everything else of a scan (tables, validation, fold, ordering, copies)
+// is left free to run beside the next scan's kernel.
+static std::mutex g_chain_lock;
+static hipEvent_t g_chain_done = nullptr;         // recorded behind the main kernel enqueued last
+static const kvq_scan *g_chain_owner = nullptr;   // (the event is its: forgotten when that scan goes away)
+
+static int chain_wait(kvq_scan *s)
+{
+    std::lock_guard<std::mutex> l(g_chain_lock);
+    if (g_chain_done && g_chain_owner != s) KVQ_HIP(hipStreamWaitEvent(s->stream, g_chain_done, 0));
+    return KVQ_OK;
+}
+static void chain_publish(kvq_scan *s, hipEvent_t done)
+{
+    std::lock_guard<std::mutex> l(g_chain_lock);
+    g_chain_done = done; g_chain_owner = s;
+}
+static void chain_forget(const kvq_scan *s)
+{
+    std::lock_guard<std::mutex> l(g_chain_lock);
+    if (g_chain_owner == s) { g_chain_done = nullptr; g_chain_owner = nullptr; }
+}
+
 // timing events are kept for the next scan of the same handle (creating a pair costs several microseconds)
 static void drop_events(kvq_scan *s, bool destroy = false)
 {
     for (auto *v : { &s->ev_all, &s->ev_main }) { s->ev_free.insert(s->ev_free.end(), v->begin(), v->end()); v->clear(); }
     if (destroy) {
+        chain_forget(s);
         for (auto &e : s->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         s->ev_free.clear();
     }
@@ -313,6 +350,7 @@ static void drop_events(kvq_scan *s, bool destroy = false)
 extern "C" void kvq_scan_destroy(kvq_scan *s)
 {
     if (!s) return;
+    g_live_scans--;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     drop_events(s, true);
     if (s->own_ctr && s->d_ctr) (void)hipFree(s->d_ctr);
@@ -424,6 +462,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     bool hist_done = false;
     if (use_seeded) {
         if ((rc = new_event_pair(s, s->ev_main))) return rc;
+        if ((rc = chain_wait(s))) return rc;
         KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream));
         KvqParams PS = P;                          // counters and error of this batch are staged until it is validated
         PS.ctr = s->d_stage_ctr; PS.err = s->d_err_stage;
@@ -431,6 +470,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
         if ((rc = kvq_seeded_launch(s, PS, d_data, nbytes, d_co, nchunks, fpos_base, maxchunk))) return rc;
         s->batches[batch_no].skip_at = s->cur_skip_at; s->batches[batch_no].tile_bytes = s->tile_bytes;
         KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
+        chain_publish(s, s->ev_main.back().second);
         s->main_launches++; s->path_bits |= 1;
         hist_done = true;
     }
