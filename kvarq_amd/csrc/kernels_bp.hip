@@ -25,6 +25,7 @@
 // a comment line in the ISA text (tools/isa_marks.py counts the instructions between two of them)
 #define KVQ_MARK(name) asm volatile("; KVQMARK " name)
 #define BP_WIN (ST_BUF + ST_BLK)   // bytes of text a tile's planes cover: 512 blocks of 80
+#define BP_Q1_KIND 25               // bit of a candidate word that says "fixed block, all-positions index"
 #define BP_QW 96                   // candidates per wave and stretch
 #define BP_Q2W 96                  // work items per wave and stretch
 #define BP_NLCAP 1920              // newlines per window (beyond: the tile raises its fallback flag)
@@ -43,7 +44,7 @@ struct BpLds {
     uint32_t hist[KVQ_RL_BINS / 2];      // read-length histogram, two 16-bit bins per word
     union {
         struct {
-            uint32_t q1[BP_QCAP];        // candidate: read (9 bits) | position in the read << 9 (12 bits) | kind << 21
+            uint32_t q1[BP_QCAP];        // candidate: read (9 bits) | position in the read << 9 (16 bits: a read may fill the window) | kind << 25
             uint32_t q2[BP_Q2CAP];       // work item: candidate << 22 | index entry
         };
         uint32_t nlp[BP_WIN / 32 + 8];   // newline plane, 1 bit per byte: lives from P0 to the newline list (P1), the queues from P3 on
@@ -717,8 +718,8 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                             if (idx < BP_QW) q1[idx] = k | ((uint32_t)(SS * (ee + j)) << 9);        // beyond the cap: dropped, the stretch is redone in halves
                             idx++;
                         }
-                        if (hh) { if (idx < BP_QW) q1[idx] = k | ((gl * SK) << 9) | (1u << 21); idx++; }
-                        if (th && idx < BP_QW) { const uint32_t pt = (uint32_t)(rl - ((int)gl + 1) * SK); q1[idx] = k | (pt << 9) | (1u << 21); }
+                        if (hh) { if (idx < BP_QW) q1[idx] = k | ((gl * SK) << 9) | (1u << BP_Q1_KIND); idx++; }
+                        if (th && idx < BP_QW) { const uint32_t pt = (uint32_t)(rl - ((int)gl + 1) * SK); q1[idx] = k | (pt << 9) | (1u << BP_Q1_KIND); }
                         qn += tot;
                     }
                 }
@@ -732,7 +733,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                         const uint64_t mm = __ballot(hit);
                         if (mm) {
                             const uint32_t idx = qn + (uint32_t)__popcll(mm & kvq_lanemask_lt());
-                            if (hit && idx < BP_QW) q1[idx] = k | ((uint32_t)pp << 9) | (1u << 21);
+                            if (hit && idx < BP_QW) q1[idx] = k | ((uint32_t)pp << 9) | (1u << BP_Q1_KIND);
                             qn += (uint32_t)__popcll(mm);
                         }
                     }
@@ -759,8 +760,8 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                     uint32_t en0 = 0, ne = 0;
                     if (qi < qn_ok) {
                         const uint32_t cd = q1[qi];
-                        const uint32_t code = cdp_code8((S.rinfo[cd & 511u] & 0xFFFFu) + ((cd >> 9) & 4095u));
-                        const GlbWords st = (cd >> 21) ? start_all : start_anc;
+                        const uint32_t code = cdp_code8((S.rinfo[cd & 511u] & 0xFFFFu) + ((cd >> 9) & 0xFFFFu));
+                        const GlbWords st = (cd >> BP_Q1_KIND) ? start_all : start_anc;
                         en0 = st[code]; ne = st[code + 1u] - en0;
                     }
                     const uint32_t inc = kvq_wave_incl_scan(ne);
@@ -784,7 +785,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                         if (active) {
                             const uint32_t it = q2[ii];
                             const uint32_t cd = q1[it >> 22];
-                            rec = cd & 511u; p = (int)((cd >> 9) & 4095u); kind = cd >> 21;
+                            rec = cd & 511u; p = (int)((cd >> 9) & 0xFFFFu); kind = cd >> BP_Q1_KIND;
                             en = (kind ? ent_all : ent_anc)[it & 0x3FFFFFu];
                         }
                         verify_item_bp(H, S, text, active, rec, p, kind, en, tile_fpos, SS);

@@ -570,3 +570,42 @@ def test_dense_table_overflows_the_candidate_queues_gracefully():
     assert (a['counters'] == b['counters']).all()
     assert len(a['hits']) > 300
     t.close()
+
+
+def test_reads_longer_than_4095_bases_keep_their_late_candidates(tmp_path):
+    """a read may fill a tile's window (tens of kilobases): candidate positions beyond 4095 must survive the
+    queue (they were once kept in twelve bits: hits deep in a long read were lost, others reported twice).
+    Found by tools/fuzz_parity.py, seeds 20325, 20667, 20774, 21304 of the seeded campaign."""
+    import random
+    rnd = random.Random(5)
+    genome = ''.join(rnd.choice('ACGT') for _ in range(12000))
+    recs = []
+    for i, (st, L) in enumerate([(100, 4200), (3000, 9000), (0, 4096), (2000, 4097), (500, 6000), (7000, 150)]):
+        recs.append('@r%d\n%s\n+\n%s\n' % (i, genome[st:st + L], 'I' * L))
+    data = ''.join(recs).encode()
+    seqs = [genome[a:a + n].encode() for a, n in ((100 + 4175, 25), (100 + 79, 25), (3000 + 8344, 25), (3000 + 8087, 39),
+                                                  (4090, 25), (6050, 51), (6400, 25), (11000, 100), (2000 + 4072, 25))]
+    p = tmp_path / 'long.fastq'
+    p.write_bytes(data)
+    cfg = dict(cases.PRODUCT, maxerrors=2, minoverlap=25, minreadlength=25, Amin='#', nthreads=1)
+    engine.config(**cfg)
+    r = engine.findseqs(str(p), seqs)
+    o = O.findseqs(str(p), seqs, **cfg)
+    assert len(o['hits']) >= 12 and max(-h.seq_pos for h in o['hits']) > 8000
+    assert tuple(r['hits']) == tuple(o['hits'])
+    assert [bytes(h) for h in r['hitseqs']] == o['hitseqs'] and r['stats'] == o['stats']
+    # the records that fit one tile's window together, as a device batch: the seed-filter kernel itself took
+    # these reads (no tile was handed to the exhaustive kernels)
+    data = ''.join(recs[:3] + recs[5:]).encode()
+    (tmp_path / 'fit.fastq').write_bytes(data)
+    o = O.findseqs(str(tmp_path / 'fit.fastq'), seqs, **cfg)
+    assert max(-h.seq_pos for h in o['hits']) > 8000
+    t = scan.Table(seqs, **{k: v for k, v in cfg.items() if k != 'nthreads'})
+    s = scan.Scanner(t)
+    arr = np.frombuffer(data, dtype=np.uint8)
+    d = scan.DeviceBuffer(arr.nbytes); d.upload(arr)
+    s.scan_device(d.ptr, arr.nbytes, scan.chunk_offsets(arr))
+    q = s.finish()
+    assert q['path'] == dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False), q['path']
+    assert tuple(q['hits']) == tuple(o['hits'])
+    s.close(); t.close(); d.free()
