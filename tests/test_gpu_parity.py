@@ -205,7 +205,26 @@ def test_hit_arena_overflow_is_transparent():
     assert r['n_hits'] == 40000 * 60
     assert int(r['counters'][t.off_nseqhits]) == 40000 * 60
     assert r['coverage'].tolist() == [40000 * 60] * 3
-    s.close(); t.close(); d.free()
+    s.close(); d.free()
+    # the same through host batches: the library cannot replay what it no longer holds (KVQ_ERR_RESCAN,
+    # include/kvarq_hip.h); Scanner.finish feeds its batches again to the enlarged arena
+    s = scan.Scanner(t)
+    half = (len(data) // 2 // len(cases.rec('x', read, 'I' * len(read)))) * len(cases.rec('x', read, 'I' * len(read)))
+    s.scan_host(arr[:half])
+    s.scan_host(arr[half:], fpos_base=half)
+    r = s.finish(hits=False)
+    assert r['n_hits'] == 40000 * 60 and int(r['counters'][t.off_nseqhits]) == 40000 * 60
+    assert r['coverage'].tolist() == [40000 * 60] * 3
+    fp = scan._view(_lib.lib().kvq_scan_hit_file_pos(s.h), r['n_hits'], __import__('ctypes').c_int64, np.int64)
+    assert int(fp[0]) == 3 and int(fp[-1]) == len(data) - len(cases.rec('x', read, 'I' * len(read))) + 3 and bool((np.diff(fp) >= 0).all())      # ('@x\\n': the bases begin three bytes into a record)
+    # and a C caller that does not replay is told so
+    s2 = scan.Scanner(t)
+    L = _lib.lib()
+    co = scan.chunk_offsets(arr)
+    assert L.kvq_scan_host(s2.h, arr.ctypes.data, arr.nbytes, co.ctypes.data_as(__import__('ctypes').POINTER(__import__('ctypes').c_int64)), len(co) - 1, 0) == 0
+    rc = L.kvq_scan_finish(s2.h)
+    assert rc != 0 and _lib.last_error()[0] == _lib.ERR_RESCAN
+    s2.close(); s.close(); t.close()
 
 
 def test_many_hits_per_read_come_back_in_reference_order():
