@@ -70,9 +70,10 @@ def main():
     ap.add_argument('--table', default='MTBC', choices=['MTBC', 'MTBC+barcodes'])
     ap.add_argument('--table-scale', type=int, default=1)
     ap.add_argument('--exhaustive', action='store_true', help='force the exhaustive kernel for every sequence')
-    ap.add_argument('--pipeline', type=int, default=3,
+    ap.add_argument('--pipeline', type=int, default=0,
                     help='scans in flight: step k+1 is enqueued (on its own scan object and stream) before the results of step k '
-                         'are waited for, so the GPU goes from one scan kernel to the next while the host collects a step (1: strictly one after the other)')
+                         'are waited for, so the GPU goes from one scan kernel to the next while the host collects a step '
+                         '(1: strictly one after the other; default: 3 when a step is one batch, else 1 -- the batches of a step already follow each other on one stream)')
     ap.add_argument('--batch-bytes', type=int, default=(1 << 32) - (1 << 20), help='largest batch handed to kvq_scan_device')
     ap.add_argument('--preheat', type=int, default=30, help='untimed scans before the warmup steps (the GPU clocks take ~10 steps = 20 ms to settle in a fresh process)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -144,7 +145,7 @@ def main():
         batches.append((base, int(offs[j]) - base, (offs[i:j + 1] - base).copy()))
 
     table = scan.Table(seqs, **cfg)
-    depth = max(1, args.pipeline)
+    depth = args.pipeline if args.pipeline > 0 else (3 if len(batches) == 1 else 1)
     ctrs = None
     reduce_by = None
     scanners = []

@@ -13,8 +13,8 @@ B="python3 $R/bench.py"
 BP="$B --preheat 0"          # counter passes: every launch is counted, no need to heat the clocks
 step() { echo "== $1" >> $O/progress.txt; }
 
-step bench;  cd $R && timeout -k 10 400 python3 bench.py > $O/bench_n1.json 2> $O/bench.err; cd /tmp
 step stats;  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 5 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
+step stats1; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- $B --pipeline 1 --steps 5 --warmup 1 --no-cpu-baseline > $O/stats1.log 2>&1
 step fetch;  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
 step write;  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
 step sq1;    timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq1 -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/sq1.log 2>&1
@@ -22,8 +22,10 @@ step sq2;    timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS
 cd $R
 python3 tools/pmc_traffic.py $O/fetch $O/write 10000000 325 > $O/pmc_traffic.json
 python3 tools/pmc_sum.py $O/sq1 kvq_scan_ > $O/pmc_sq_counters.txt; python3 tools/pmc_sum.py $O/sq2 kvq_scan_ >> $O/pmc_sq_counters.txt
-python3 tools/trace_step.py $O/stats 1 > $O/step_timeline.txt
+python3 tools/trace_step.py $O/stats1 1 > $O/step_timeline.txt                 # one step at a time: the tail kernels at their own speed
+python3 tools/trace_step.py $O/stats 2 > $O/step_timeline_pipelined.txt        # the default: three steps in flight
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/rocprofv3_kernel_stats.csv 2>/dev/null
+cp $(ls $O/stats1/*/*kernel_stats.csv | head -1) $O/rocprofv3_kernel_stats_pipeline1.csv 2>/dev/null
 step stamps; KVQ_DBG=16 timeout -k 10 200 python3 tools/phase_stamps.py > $O/phase_stamps.txt 2>&1
 step hosttimes; timeout -k 10 200 python3 tools/step_host_times.py > $O/step_host_times.txt 2>&1
 step phases
@@ -32,24 +34,17 @@ for d in 0 1 2 32; do
   echo "== KVQ_DBG=$d (0: whole kernel, 1: no verify, 2: no filter and verify, 32: front end only); 5 M reads per launch" >> $O/pmc_phases.txt
   python3 tools/pmc_sum.py $O/ph$d kvq_scan_ >> $O/pmc_phases.txt
 done
-step configs
-: > $O/other_configs.txt
-for args in "--reads 1000000" "--reads 40000000" "--readlen 300 --table MTBC+barcodes" "--table-scale 8 --reads 4000000" "--table-scale 32 --reads 4000000"; do
-  timeout -k 10 300 python3 bench.py $args --no-cpu-baseline --steps 5 > $O/cfg.json 2> $O/cfg.err
-  python3 - "$args" $O/cfg.json >> $O/other_configs.txt <<'PY'
-import json, sys
-d = json.load(open(sys.argv[2])); r = d['roofline']
-print('%-44s step %.3f ms  kernel %.3f ms/launch (%d launch/step, %.3f GB)  roofline %.4f  %.3f G reads/s' % (
-    sys.argv[1], d['ms_per_step'], r['avg_launch_ms'], r['launches_per_step'], r['algorithmic_bytes_per_launch'] / 1e9, r['frac'], d['value'] / 1e9))
-PY
-done
+step configs; bash tools/other_configs.sh > /dev/null 2>&1
 step filerate; timeout -k 10 200 python3 tools/file_rate.py > $O/file_rate.txt 2>&1
 step clock; bash tools/clock_pmc.sh $TAG/clk > $O/clock.txt 2>&1
 step ubench
 ( cd tools/ubench && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o valu_rate valu_rate.hip 2>/dev/null && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o issue_rate issue_rate.hip 2>/dev/null
   timeout -k 10 120 ./valu_rate > $O/valu_rate.txt 2>&1 && timeout -k 10 120 ./issue_rate > $O/issue_rate.txt 2>&1 )
+# the bench line last: it quotes the traffic file made above (same sources)
+step bench;  cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json; timeout -k 10 400 python3 bench.py > $O/bench_n1.json 2> $O/bench.err
+timeout -k 10 400 python3 bench.py --pipeline 1 --no-cpu-baseline > $O/bench_n1_pipeline1.json 2>> $O/bench.err
 step done
-for f in bench_n1.json rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt clock.txt valu_rate.txt issue_rate.txt; do
+for f in bench_n1.json bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt clock.txt valu_rate.txt issue_rate.txt; do
   echo "cp gpurun_out/$TAG/$f profiles/${TAG}_$f"
 done
 cat $O/bench_n1.json
