@@ -107,7 +107,13 @@ typedef struct kvq_scan kvq_scan;
 
 /* d_counters: device buffer of kvq_counters_len() int64 owned by the caller
  * (e.g. a torch tensor that is all-reduced afterwards), zeroed by the caller;
- * NULL = the scan allocates and zeroes its own. */
+ * NULL = the scan allocates and zeroes its own.
+ *
+ * Several scan objects may be alive at once (each has its own stream): a caller may enqueue the next job
+ * (kvq_scan_reset + kvq_scan_device) on one object before it waits for kvq_scan_finish of another -- the
+ * reference's counterpart is a caller that starts the next file while it post-processes the last result.
+ * The persistent scan kernels of a process are chained (one at a time, in the order they were enqueued);
+ * the small kernels of a finish run beside the next scan. */
 kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters);
 void      kvq_scan_destroy(kvq_scan *s);
 
