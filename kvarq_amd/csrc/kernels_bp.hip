@@ -507,23 +507,29 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 const uint64_t mk = __ballot(ok);
                 if (mk) jn = (uint32_t)(__ffsll((long long)mk) - 1);
             }
+            // a tile whose LAST records do not fit its window (a record longer than the look-ahead) keeps the
+            // records that do and leaves the rest; one that overflows its tables (newlines, records) keeps none.
+            // What it leaves is scanned again after the kernel (kvq_collect_skipped): TR_FLAG_SKIPPED, and where the
+            // first record it left begins (batch offset + 1; 0: it kept none) in the second report word
+            uint32_t left = 0u;
             if (jn != TR_NONE) {
                 if (jn <= n_owned) nrec = (n_owned - jn) / 4u + 1u;
                 if (nrec > 0 && jn + 4u * nrec > n_nl) {
                     const uint32_t fit = n_nl >= jn ? (n_nl - jn) / 4u : 0u;
-                    if (load_hi < Jb || n_all > BP_NLCAP) fallback = 1u;
+                    if (load_hi < Jb) left = 1u;
+                    if (n_all > BP_NLCAP) fallback = 1u;
                     nrec = fit;
                 }
                 if (nrec > ST_RCAP) { nrec = ST_RCAP; fallback = 1u; }
             }
-            // a tile that cannot take all its records takes none: they are scanned again after the kernel (these tiles only)
-            if (fallback) nrec = 0;
+            if (fallback) { nrec = 0; left = 1u; }
             // thread 0 reports; the last wave (which holds the fewest reads) draws the tile after next: wanted
             // at the end of this tile, and the answer is not waited for before that
             if (tid == 0 || tid == ST_THREADS - 64) {
                 const BpArgsPtr A = bp_args(A_);
                 if (tid == 0) {
-                    A->tile_report[g] = (n_owned & 0xFFFFu) | ((jn & 0xFFu) << 16) | (fallback ? TR_FLAG_SKIPPED : 0u);
+                    A->tile_report[g] = (n_owned & 0xFFFFu) | ((jn & 0xFFu) << 16) | (left ? TR_FLAG_SKIPPED : 0u) | (left && nrec ? TR_FLAG_PARTIAL : 0u);
+                    if (left) A->tile_report[ntiles + g] = nrec ? g0 - ST_PRE + (uint32_t)S.nl[jn + 4u * nrec - 1u] + 2u : 0u;
                     S.records += nrec;
                 } else if (shards_left) drawn = atomicAdd(&A->tile_ctr[my_shard * BP_SHARD_STRIDE], 1u);
             }
@@ -877,14 +883,14 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     const uint32_t per_cu = ix->variant ? 2u : 4u;
     const uint32_t grid_full = cus * per_cu, grid_shared = grid_full - cus / 8u;
     const uint32_t grid_cap = grid_env ? grid_env : (!ix->variant && kvq_live_scans() > 1) ? grid_shared : grid_full;
-    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 20 + 24576 + KVQ_SKIP_CAP * 8 > s->pool.cap) {       // run_batch made the room
+    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 24 + 24576 + KVQ_SKIP_CAP * 16 > s->pool.cap) {       // run_batch made the room
         kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;
     }
     // first tile of every chunk, then the parameter block: one copy
     const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
     const size_t ctr_b = 256 + 4 * BP_SHARDS * BP_SHARD_STRIDE;                  // the tile counters (kvq_scan_seeded: one; kvq_scan_bp: BP_SHARDS)
     const size_t first_at = s->pool.take(first_b + sizeof(BpArgs) + ctr_b);      // ... and the tile counters behind it
-    const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 4), skip_at = s->pool.take(KVQ_SKIP_CAP * 8);
+    const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 8), skip_at = s->pool.take(KVQ_SKIP_CAP * 16);      // (report: a word per tile, then a word per tile for the records a skipping tile kept)
     s->cur_skip_at = skip_at; s->cur_first_at = first_at; s->cur_ntiles = (uint32_t)nt;
     uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
     uint64_t acc = 0;
@@ -956,7 +962,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     }
     if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
-                       d_first, d_report, s->cur_fail, ix->variant ? (uint2 *)nullptr : reinterpret_cast<uint2 *>(s->pool.d + skip_at));
+                       d_first, d_report, s->cur_fail, ix->variant ? (uint4 *)nullptr : reinterpret_cast<uint4 *>(s->pool.d + skip_at));
     KVQ_HIP(hipGetLastError());
     if (getenv("KVQ_DBG_REPORT")) {
         // diagnostic: replay kvq_validate_tiles on the host and name the tiles it rejects

@@ -140,24 +140,35 @@ kvq_collect_skipped(const uint8_t *__restrict__ data, const KvqSkippedTile *__re
     uint32_t idx = T.seen;                       // number (within the chunk) of the next newline met
     bool collecting = T.first != 0u;             // tile 0: the chunk's first record
     uint32_t rstart = T.a, cnt = 0, nlb[4] = { 0, 0, 0, 0 };
-    for (uint32_t p = T.own_begin; p < T.b; p += 64u) {
-        if (p >= T.own_end && !collecting) break;
-        const bool is_nl = p + (uint32_t)lane < T.b && data[p + (uint32_t)lane] == '\n';
-        unsigned long long m = __ballot(is_nl);
-        while (m) {                              // (the same for every lane: the mask is the wave's)
-            const uint32_t pos = p + (uint32_t)(__ffsll((long long)m) - 1); m &= m - 1ull;
-            if (collecting) {
-                nlb[cnt++] = pos;
-                if (cnt == 4u) {
-                    if (lane == 0) {
-                        const unsigned int r = atomicAdd(rec_count, 1u);
-                        if (r < rec_cap) { rec_start[r] = rstart; nl4[4 * (size_t)r] = nlb[0]; nl4[4 * (size_t)r + 1] = nlb[1]; nl4[4 * (size_t)r + 2] = nlb[2]; nl4[4 * (size_t)r + 3] = nlb[3]; }
+    for (uint32_t p4 = T.own_begin; p4 < T.b; p4 += 256u) {
+        if (p4 >= T.own_end && !collecting) break;
+        // (four loads in flight: a record of thousands of bytes is a chain of memory round trips otherwise)
+        bool nl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t q = p4 + 64u * (uint32_t)k + (uint32_t)lane;
+            nl[k] = q < T.b && data[q] == '\n';
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t p = p4 + 64u * (uint32_t)k;
+            if (p >= T.b || (p >= T.own_end && !collecting)) break;
+            unsigned long long m = __ballot(nl[k]);
+            while (m) {                              // (the same for every lane: the mask is the wave's)
+                const uint32_t pos = p + (uint32_t)(__ffsll((long long)m) - 1); m &= m - 1ull;
+                if (collecting) {
+                    nlb[cnt++] = pos;
+                    if (cnt == 4u) {
+                        if (lane == 0) {
+                            const unsigned int r = atomicAdd(rec_count, 1u);
+                            if (r < rec_cap) { rec_start[r] = rstart; nl4[4 * (size_t)r] = nlb[0]; nl4[4 * (size_t)r + 1] = nlb[1]; nl4[4 * (size_t)r + 2] = nlb[2]; nl4[4 * (size_t)r + 3] = nlb[3]; }
+                        }
+                        collecting = false;
                     }
-                    collecting = false;
                 }
+                if ((idx & 3u) == 3u && pos < T.own_end) { collecting = true; rstart = pos + 1u; cnt = 0; }     // (an owned newline that ends a record: the next one starts behind it)
+                idx++;
             }
-            if ((idx & 3u) == 3u && pos < T.own_end) { collecting = true; rstart = pos + 1u; cnt = 0; }     // (an owned newline that ends a record: the next one starts behind it)
-            idx++;
         }
     }
 }
@@ -202,8 +213,10 @@ __device__ __forceinline__ void run_feed(RunState &st, uint64_t good, int nbits,
 extern "C" __global__ void __launch_bounds__(256)
 kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, uint32_t nrec,
                  const uint32_t *__restrict__ nl4, const uint32_t *__restrict__ rec_start,
-                 uint32_t *__restrict__ read_off, int32_t *__restrict__ read_len, int32_t count)
+                 uint32_t *__restrict__ read_off, int32_t *__restrict__ read_len, int32_t count, uint32_t rpw)
 {
+    // rpw: consecutive records per wave (KVQ_TRIM_RPW for a batch of ordinary reads; 1 for the few, possibly very
+    // long records of skipped tiles)
     __shared__ unsigned int hist[KVQ_RL_BINS];
     __shared__ int longest;
     for (int i = threadIdx.x; i < KVQ_RL_BINS; i += blockDim.x) hist[i] = 0;
@@ -212,8 +225,8 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
 
     const int lane = kvq_lane();
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t g_begin = wave * KVQ_TRIM_RPW;
-    for (uint32_t g = g_begin; g < g_begin + KVQ_TRIM_RPW && g < nrec; g++) {
+    const uint32_t g_begin = wave * rpw;
+    for (uint32_t g = g_begin; g < g_begin + rpw && g < nrec; g++) {
         const uint32_t rstart = rec_start[g];
         const uint32_t n0 = nl4[4 * (size_t)g], n1 = nl4[4 * (size_t)g + 1], n2 = nl4[4 * (size_t)g + 2], n3 = nl4[4 * (size_t)g + 3];
         const uint32_t sread = n0 + 1u, plus = n1 + 1u, sscore = n2 + 1u;
@@ -227,12 +240,22 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
         // score line including its '\n': bytes [sscore, n3]
         const uint32_t qlen = n3 - sscore + 1u;
         RunState st; st.in_run = 1; st.run_start = 0; st.best = 0; st.best_start = 0;   // qtr starts at startscore (1055)
-        for (uint32_t o = 0; o < qlen; o += 64u) {
-            const uint32_t i = o + lane;
-            const bool ok = (i < qlen) && ((int)(int8_t)data[sscore + i] >= P.amin);
-            const uint64_t good = __ballot(ok);
-            const int nbits = (qlen - o) < 64u ? (int)(qlen - o) : 64;
-            run_feed(st, good, nbits, o);
+        for (uint32_t o4 = 0; o4 < qlen; o4 += 256u) {
+            // (four loads in flight: a score line of thousands of bytes is a chain of memory round trips otherwise)
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = o4 + 64u * (uint32_t)k + (uint32_t)lane;
+                ok[k] = (i < qlen) && ((int)(int8_t)data[sscore + i] >= P.amin);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t o = o4 + 64u * (uint32_t)k;
+                if (o >= qlen) break;
+                const uint64_t good = __ballot(ok[k]);
+                const int nbits = (qlen - o) < 64u ? (int)(qlen - o) : 64;
+                run_feed(st, good, nbits, o);
+            }
         }
         const int rl = st.best;
         if (lane == 0) {
@@ -251,8 +274,8 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
     if (threadIdx.x == 0) {
         if (longest >= 0) atomicMax(&P.ctr[KVQ_CTR_LONGEST_], (unsigned long long)(longest + 1));
         // records of this block (add_records_parsed, 1187)
-        const uint32_t first = blockIdx.x * 4u * KVQ_TRIM_RPW;
-        const uint32_t n = nrec > first ? (nrec - first < 4u * KVQ_TRIM_RPW ? nrec - first : 4u * KVQ_TRIM_RPW) : 0u;
+        const uint32_t first = blockIdx.x * 4u * rpw;
+        const uint32_t n = nrec > first ? (nrec - first < 4u * rpw ? nrec - first : 4u * rpw) : 0u;
         if (n) atomicAdd(&P.ctr[KVQ_CTR_RECORDS_], (unsigned long long)n);
     }
 }
@@ -304,7 +327,7 @@ kvq_match_all(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, 
         }
         const int nC = (rl > seql ? rl - seql : seql - rl) + 1;   // 1147 / 1163
         const int njobs = nA + nB + nC;
-        for (int j0 = 0; j0 < njobs; j0 += 64) {
+        for (int j0 = 64 * (int)blockIdx.z; j0 < njobs; j0 += 64 * (int)gridDim.z) {      // (gridDim.z > 1: the alignments of one long read shared out as well)
             const int j = j0 + lane;
             bool hit = false; int spos = 0, len = 0; uint32_t key = 0;
             if (j < njobs) {

@@ -61,8 +61,9 @@
 // tile report word for kvq_validate_tiles
 #define TR_NONE 0xFFu              // no record starts in this tile
 #define TR_FLAG_FALLBACK 0x2000000u   // the tile could not do its work (one read flooded a wave's queues): the batch is scanned again, exhaustively
-#define TR_FLAG_SKIPPED 0x4000000u    // the tile has left ALL its records alone (a record longer than the look-ahead, more newlines or
-                                      // records than the tile's tables hold): only its records are scanned again (kvq_collect_skipped)
+#define TR_FLAG_SKIPPED 0x4000000u    // the tile has left records alone (the last ones, when a record is longer than the look-ahead; all
+                                      // of them, when it holds more newlines or records than its tables): those are scanned again (kvq_collect_skipped)
+#define TR_FLAG_PARTIAL 0x8000000u    // ... but it did scan the records in front of those (so its speculated first record counts, and is checked)
 #define KVQ_SKIP_CAP 1024u            // skipped tiles a batch may have before it is scanned again as a whole
 
 struct SeedTables {
@@ -1082,7 +1083,7 @@ __host__ __device__ static inline bool kvq_tile_report_bad(uint32_t rep, bool fi
 {
     const uint32_t n_owned = rep & 0xFFFFu, jn = (rep >> 16) & 0xFFu;
     if (rep & TR_FLAG_FALLBACK) return true;
-    if (rep & TR_FLAG_SKIPPED) return false;               // (its records are found again from the exact newline count)
+    if ((rep & TR_FLAG_SKIPPED) && !(rep & TR_FLAG_PARTIAL)) return false;      // (it scanned nothing: its records are found again from the exact newline count)
     // the first record this tile owns starts behind its newline number `want` (tile 0: the chunk
     // start itself) -- if the chunk goes on for at least two more lines behind that newline: the
     // kernel wants to see the record's '+' line (P2), and a chunk that ends there has no record left
@@ -1094,10 +1095,10 @@ __host__ __device__ static inline bool kvq_tile_report_bad(uint32_t rep, bool fi
 
 extern "C" __global__ void __launch_bounds__(256)
 kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_report,
-                   unsigned int *__restrict__ spec_fail, uint2 *__restrict__ skip_list)
+                   unsigned int *__restrict__ spec_fail, uint4 *__restrict__ skip_list)
 {
-    // *spec_fail: bit 0 = the batch failed; from bit 8 on = number of skipped tiles (their numbers and the
-    // newlines of their chunk in front of them go to skip_list)
+    // *spec_fail: bit 0 = the batch failed; from bit 8 on = number of skipped tiles (their numbers, the
+    // newlines of their chunk in front of them and the records they did take go to skip_list)
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     uint32_t total = 0;                        // newlines of the chunk
@@ -1109,7 +1110,7 @@ kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, co
         if (kvq_tile_report_bad(rep, g == tile_first[c], seen, total)) bad = true;
         if ((rep & TR_FLAG_SKIPPED) && skip_list) {
             const unsigned int k = atomicAdd(spec_fail, 0x100u) >> 8;
-            if (k < KVQ_SKIP_CAP) skip_list[k] = make_uint2(g, seen); else bad = true;
+            if (k < KVQ_SKIP_CAP) skip_list[k] = make_uint4(g, seen, tile_report[tile_first[nchunks] + g], 0u); else bad = true;
         }
         seen += rep & 0xFFFFu;
     }

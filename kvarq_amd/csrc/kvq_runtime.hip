@@ -433,7 +433,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     // block, tile table and tile reports in kvq_seeded_launch, whose tiles own at least kvq_min_tile() bytes --
     // is made in one go: the pool must not move between the two)
     const size_t tiles_bound = (size_t)(nbytes / kvq_min_tile()) + (size_t)nchunks + 2;
-    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 8 + tiles_bound * 20 + 49152, s->stream))) return rc;
+    if ((rc = s->pool.reserve(((size_t)nchunks + 1) * 8 + tiles_bound * 24 + 65536, s->stream))) return rc;
     const size_t co_at = s->pool.take(((size_t)nchunks + 1) * 4);
     s->cur_co_at = co_at;
     uint32_t *co = reinterpret_cast<uint32_t *>(s->pool.h + co_at);
@@ -513,7 +513,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
             const uint32_t per_block = 4 * 16;       // KVQ_TRIM_RPW records per wave
             hipLaunchKernelGGL(kvq_trim_records, dim3((uint32_t)((R + per_block - 1) / per_block)), dim3(256), 0, s->stream, P, d_data,
                                fpos_base, (uint32_t)R, s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(),
-                               s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), hist_done ? 0 : 1);
+                               s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), hist_done ? 0 : 1, 16u);
             if (n_exh > 0) {
                 const bool main_here = !use_seeded;
                 if (main_here) { if ((rc = new_event_pair(s, s->ev_main))) return rc; KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream)); }
@@ -546,9 +546,9 @@ static int redo_skipped(kvq_scan *s, size_t b, uint32_t nskip, const uint8_t *d_
     const kvq_table *t = s->t;
     if (nskip > KVQ_SKIP_CAP) nskip = KVQ_SKIP_CAP;
     const Batch src = s->batches[b];
-    std::vector<uint2> list(nskip);
+    std::vector<uint4> list(nskip);
     KVQ_HIP(hipStreamSynchronize(s->stream));
-    KVQ_HIP(hipMemcpy(list.data(), s->pool.d + src.skip_at, (size_t)nskip * 8, hipMemcpyDeviceToHost));
+    KVQ_HIP(hipMemcpy(list.data(), s->pool.d + src.skip_at, (size_t)nskip * 16, hipMemcpyDeviceToHost));
     // tile geometry as kvq_seeded_launch made it
     const uint32_t TILE = src.tile_bytes;
     const int64_t nchunks = (int64_t)src.chunk_off.size() - 1;
@@ -569,6 +569,8 @@ static int redo_skipped(kvq_scan *s, size_t b, uint32_t nskip, const uint8_t *d_
         KvqSkippedTile T;
         T.a = a; T.b = e; T.own_begin = tn == 0 ? a : g0; T.own_end = (uint64_t)g0 + TILE < e ? g0 + TILE : e;
         T.seen = list[i].y; T.first = tn == 0 ? 1u : 0u;
+        // (the tile has scanned the records in front of list[i].z - 1: the walk begins there, at a record's first byte)
+        if (list[i].z) { T.a = T.own_begin = list[i].z - 1u; T.seen = 0; T.first = 1u; }
         tiles[i] = T;
     }
     // a record has four newlines: a tile of TILE bytes owns at most TILE / 4 of them
@@ -599,11 +601,15 @@ static int redo_skipped(kvq_scan *s, size_t b, uint32_t nskip, const uint8_t *d_
     if (R > 0) {
         if ((rc = s->d_read_off.ensure((size_t)R * 4))) return rc;
         if ((rc = s->d_read_len.ensure((size_t)R * 4))) return rc;
-        hipLaunchKernelGGL(kvq_trim_records, dim3((R + 63) / 64), dim3(256), 0, s->stream, P, d_data, src.fpos_base, (uint32_t)R,
-                           s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(), s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), 1);
+        // few records, some of them very long: a wave per record for the trim; for the matcher a record's sequences
+        // -- and, when the records are really few, its alignments too -- are shared out over many waves
+        const bool few = R <= 256;
+        const uint32_t trim_rpw = few ? 1u : 16u;
+        hipLaunchKernelGGL(kvq_trim_records, dim3((R + 4 * trim_rpw - 1) / (4 * trim_rpw)), dim3(256), 0, s->stream, P, d_data, src.fpos_base, (uint32_t)R,
+                           s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(), s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), 1, trim_rpw);
         if (!t->seeded.empty())
-            // (few reads, some of them long: a read's sequences are shared out over up to 64 waves)
-            hipLaunchKernelGGL(kvq_match_all, dim3((R + 3) / 4, (uint32_t)std::min<size_t>(t->seeded.size(), 64)), dim3(256), 0, s->stream, P, d_data, src.fpos_base, (uint32_t)R,
+            hipLaunchKernelGGL(kvq_match_all, dim3((R + 3) / 4, (uint32_t)std::min<size_t>(t->seeded.size(), few ? 1024 : 64), few ? 8u : 1u), dim3(256), 0, s->stream,
+                               P, d_data, src.fpos_base, (uint32_t)R,
                                s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), t->d_seeded.as<int32_t>(), (int32_t)t->seeded.size());
     }
     KVQ_HIP(hipMemcpyAsync(s->d_range + batch_no + 1, s->d_arena_n, 4, hipMemcpyDeviceToDevice, s->stream));

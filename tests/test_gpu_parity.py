@@ -628,3 +628,49 @@ def test_reads_longer_than_4095_bases_keep_their_late_candidates(tmp_path):
     assert q['path'] == dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False), q['path']
     assert tuple(q['hits']) == tuple(o['hits'])
     s.close(); t.close(); d.free()
+
+
+@pytest.mark.parametrize('malformed', [False, True])
+def test_a_tile_that_keeps_some_records_still_answers_for_its_first_one(tmp_path, malformed):
+    """long records: a tile whose last record outgrows its window keeps the records in front of it and leaves the
+    rest to the exhaustive kernels -- so its speculated first record counts and must be validated like any tile's.
+    (tools/fuzz_parity.py seed 131412: the first record of such a tile had a malformed '+' line, the speculation
+    skipped it, and nobody reported the error.)"""
+    import random
+    rnd = random.Random(7)
+    genome = ''.join(rnd.choice('ACGT') for _ in range(20000))
+    lens = [4200, 9000, 9000, 1024, 1023, 4200, 4200, 4200, 4200, 1500, 1500, 4200, 9000, 600, 1023, 9000, 600]
+    recs, at = [], 0
+    for i, L in enumerate(lens):
+        st = rnd.randrange(0, len(genome) - L)
+        recs.append('@r%d\n%s\n+\n%s\n' % (i, genome[st:st + L], 'I' * L))
+    if malformed:
+        recs[8] = recs[8].replace('\n+\n', '\n-\n', 1)
+    data = ''.join(recs).encode()
+    starts = [sum(len(r) for r in recs[:i]) for i in range(len(recs))]
+    assert 73280 < starts[8] < 77440                        # the record sits at the head of the third tile (tiles own 36640 bytes here)
+    seqs = [genome[a:a + n].encode() for a, n in ((100, 150), (5000, 51), (12000, 25), (15000, 300))]
+    p = tmp_path / 'partial.fastq'
+    p.write_bytes(data)
+    cfg = dict(cases.PRODUCT, maxerrors=2, minoverlap=25, minreadlength=25, Amin='#', nthreads=1)
+    engine.config(**cfg)
+    if malformed:
+        with pytest.raises(O.OracleFormatError) as eo:
+            O.findseqs(str(p), seqs, **cfg)
+        with pytest.raises(FastqFileFormatException) as eg:
+            engine.findseqs(str(p), seqs)
+        assert str(eg.value) == str(eo.value) and 'fpos=%d' % (starts[8] + len('@r8\n') + 4200 + 1) in str(eg.value)
+        return
+    o = O.findseqs(str(p), seqs, **cfg)
+    r = engine.findseqs(str(p), seqs)
+    assert len(o['hits']) > 0 and tuple(r['hits']) == tuple(o['hits'])
+    assert [bytes(h) for h in r['hitseqs']] == o['hitseqs'] and r['stats'] == o['stats']
+    t = scan.Table(seqs, **{k: v for k, v in cfg.items() if k != 'nthreads'})
+    s = scan.Scanner(t)
+    arr = np.frombuffer(data, dtype=np.uint8)
+    d = scan.DeviceBuffer(arr.nbytes); d.upload(arr)
+    s.scan_device(d.ptr, arr.nbytes, scan.chunk_offsets(arr))
+    q = s.finish()
+    assert q['path'] == dict(seeded=True, exhaustive=True, rescanned=False, tiles_rescanned=True), q['path']
+    assert tuple(q['hits']) == tuple(o['hits']) and q['stats']['records_parsed'] == len(lens)
+    s.close(); t.close(); d.free()
