@@ -39,7 +39,10 @@ static int rccl_load()
     if (g_rccl.lib) return KVQ_OK;
     const char *names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1" };
     void *h = nullptr;
-    for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    // an RCCL that the process has loaded already (a host that runs torch.distributed has its own copy) is the one to
+    // use: one instance per process; only otherwise is one looked for
+    for (const char *n : { "librccl.so.1", "librccl.so" }) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!h) for (const char *n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!h) { kvq_set_error(KVQ_ERR_RUNTIME, "cannot load librccl.so: %s", dlerror()); return KVQ_ERR_RUNTIME; }
     KvqRccl r; r.lib = h;
 #define KVQ_SYM(field, name) do { *(void **)(&r.field) = dlsym(h, name); if (!r.field) { kvq_set_error(KVQ_ERR_RUNTIME, "librccl.so lacks %s", name); dlclose(h); return KVQ_ERR_RUNTIME; } } while (0)
