@@ -8,6 +8,8 @@ the C ABI exactly as a caller of ``kvarq.engine`` would reach it, against
 Bit-exact everywhere: hits, hit bytes, per-sequence counters, read-length
 histogram, coverage and mutation counts.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -18,6 +20,11 @@ from oracle import oracle as O
 from util import expected, check_against_expected
 
 pytestmark = pytest.mark.gpu
+
+# round 1's kernel (KVQ_KERNEL=v1, kept selectable) hands a batch with such a tile to the exhaustive kernels as a whole
+V1 = os.environ.get('KVQ_KERNEL') == 'v1'
+REDO_PATH = (dict(seeded=True, exhaustive=True, rescanned=True, tiles_rescanned=False) if V1 else
+             dict(seeded=True, exhaustive=True, rescanned=False, tiles_rescanned=True))
 
 CASES = cases.all_cases(big=True)
 
@@ -402,7 +409,7 @@ def test_seeded_and_exhaustive_kernels_agree_and_paths_are_as_expected(tmp_path)
     # (a tile and its look-ahead span 40.8 kB): that tile's records are scanned again by the exhaustive kernels
     import os
     if os.environ.get('KVQ_KERNEL') != 'v1' and not os.environ.get('KVQ_TILE'):   # (the bit-plane kernel, or another tile size, cuts the tiles elsewhere)
-        want_path['long_reads_straddle'] = dict(seeded=True, exhaustive=True, rescanned=False, tiles_rescanned=True)   # (the one tile's records only)
+        want_path['long_reads_straddle'] = REDO_PATH   # (the one tile's records only)
     for name, wp in want_path.items():
         case = cases.by_name()[name.replace('_straddle', '')]
         files = case.materialize(tmp_path)
@@ -522,7 +529,7 @@ def test_one_long_record_costs_its_tile_not_the_batch():
             best = min(best, time.perf_counter() - t0)
         times[name] = best
         if name == 'long':
-            assert r['path'] == dict(seeded=True, exhaustive=True, rescanned=False, tiles_rescanned=True), r['path']
+            assert r['path'] == REDO_PATH, r['path']
             assert tuple(r['hits']) == tuple(o['hits']) and r['hitseqs'] == o['hitseqs']
             assert r['coverage'].tolist() == o['coverage'] and r['mutations'].tolist() == o['mutations']
             assert r['stats']['records_parsed'] == n + 1 and r['stats']['readlengths'] == o['stats']['readlengths']
@@ -531,7 +538,7 @@ def test_one_long_record_costs_its_tile_not_the_batch():
         d.free()
     # (the redo costs a round trip to the host and a few small kernels; a rescan of the batch with the
     # exhaustive kernels took about 80 ms for these 300 k reads)
-    assert times['long'] < 2 * times['plain'] + 0.004, times
+    assert V1 or times['long'] < 2 * times['plain'] + 0.004, times
     s.close(); t.close()
 
 
@@ -671,6 +678,6 @@ def test_a_tile_that_keeps_some_records_still_answers_for_its_first_one(tmp_path
     d = scan.DeviceBuffer(arr.nbytes); d.upload(arr)
     s.scan_device(d.ptr, arr.nbytes, scan.chunk_offsets(arr))
     q = s.finish()
-    assert q['path'] == dict(seeded=True, exhaustive=True, rescanned=False, tiles_rescanned=True), q['path']
+    assert q['path'] == REDO_PATH, q['path']
     assert tuple(q['hits']) == tuple(o['hits']) and q['stats']['records_parsed'] == len(lens)
     s.close(); t.close(); d.free()
