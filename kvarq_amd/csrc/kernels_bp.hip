@@ -182,6 +182,25 @@ __device__ __forceinline__ void bp_vector(const uint4 v, uint32_t addk, uint32_t
         gf[d] = good_flags(x[d], addk);
         cc[d] = __builtin_amdgcn_udot4(x[d] & 0x06060606u, 0x40100401u, 0u, false);     // twice the 8-bit code of the four bytes
     }
+#ifdef KVQ_ABL_JUNK
+    // (ablation builds only: KVQ_ABL_JUNK extra vector instructions per 16 bytes of text -- what one more instruction costs in place)
+    {
+        uint32_t junk = x[0];
+#pragma unroll
+        for (int i = 0; i < KVQ_ABL_JUNK; i++) {
+#if KVQ_ABL_SLOW == 2
+            { uint32_t sj = 0; asm volatile("s_add_u32 %0, %0, 1" : "+s"(sj)); asm volatile("" :: "s"(sj)); }
+#elif KVQ_ABL_SLOW == 3
+            { uint32_t lj; asm volatile("ds_read_b32 %0, %1" : "=v"(lj) : "v"(junk & 0x3FCu)); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); asm volatile("" :: "v"(lj)); }
+#elif KVQ_ABL_SLOW
+            asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(junk) : "v"(x[1]));
+#else
+            asm volatile("v_add_u32 %0, %0, %1" : "+v"(junk) : "v"(x[1]));
+#endif
+        }
+        asm volatile("" :: "v"(junk));
+    }
+#endif
     nl16 = kvq_flags16(nf[0], nf[1], nf[2], nf[3]);
     g16 = kvq_flags16(gf[0], gf[1], gf[2], gf[3]);
     c32 = ((cc[0] | (cc[1] << 8)) >> 1) | ((cc[2] | (cc[3] << 8)) << 15);
@@ -325,6 +344,9 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     // bits [80 t, 80 t + 80) of the newline plane, which its own wave has written.
     __syncthreads();
 
+    // (experiment, KVQ_STAGGER: the workgroups that share a compute unit start a fraction of a tile apart, so that one's wait
+    // for its text meets another's arithmetic: workgroup b sits in slot b / 256 of its compute unit under round-robin dispatch)
+    if (const uint32_t stg = bp_args(A_)->pad_) { for (uint32_t i = 0; i < (blockIdx.x >> 8) * stg; i++) __builtin_amdgcn_s_sleep(127); }
     const uint32_t addk = (0x80u - amin) * 0x01010101u;
     uint32_t tiles_done = 0;
     // The barrier that ends a tile stands at the top of the next one, BEHIND the issue of that tile's loads:
@@ -574,7 +596,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 const uint32_t n0 = S.nl[m], n1 = S.nl[m + 1], n2 = S.nl[m + 2], n3 = S.nl[m + 3];
                 const uint32_t sread = n0 + 1u, plus = n1 + 1u, sscore = n2 + 1u;
         KVQ_MARK("trim");
-                if (gl == 0) { c0 = text[rstart]; cp = text[plus]; }
+                if (gl == 0) { if (dbg & 8u) { c0 = '@'; cp = '+'; } else { c0 = text[rstart]; cp = text[plus]; } }   // (diagnostic 8: no '@' / '+' probes -- ablation only)
                 // quality trim (1055-1068): this lane's slice of the score line is a bit range of the good plane
                 const int Q = (int)(n3 - sscore);                   // the closing '\n' is implied
                 const int per = (Q + (int)G - 1) >> lg;
@@ -648,7 +670,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
             const uint32_t wfirst = pass0 + wave * rpw;
             const uint32_t npass = wfirst < nrec ? (nrec - wfirst < rpw ? nrec - wfirst : rpw) : 0u;
             uint32_t *const q1 = S.q1 + wave * BP_QW; uint32_t *const q2 = S.q2 + wave * BP_Q2W;
-            uint32_t sub = 0, step = rpw;
+            uint32_t sub = (dbg & 128u) ? npass : 0u, step = rpw;             // (diagnostic 128: trim only)
             while (sub < npass) {
                 int minrl, me_; const __attribute__((address_space(1))) uint8_t *bmL;
                 {
@@ -845,140 +867,4 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         if (S.longest_p1) atomicMax(&ctr[KVQ_CTR_LONGEST_], (unsigned long long)S.longest_p1);
         if (S.records) atomicAdd(&ctr[KVQ_CTR_RECORDS_], (unsigned long long)S.records);
     }
-}
-
-// ---------------------------------------------------------------------------
-// launch (both scan kernels)
-// ---------------------------------------------------------------------------
-
-int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
-                      const uint32_t *d_chunk_off, int64_t nchunks, int64_t fpos_base, uint32_t max_chunk_bytes)
-{
-    (void)nbytes; (void)max_chunk_bytes;
-    SeedIndex *ix = s->t->index;
-    // tiles per chunk; the tables live in the scan's pool so that nothing here waits for the GPU
-    const std::vector<int64_t> &co = s->cur_chunk_off;
-    if (s->tile_bytes == 0) {
-        // first batch of a device-resident scan: look at the head of the text once (the choice is kept
-        // across kvq_scan_reset; host batches are sized on the host, kvq_scan_host_async)
-        const size_t n = (size_t)std::min<int64_t>(nbytes, 128 << 10);
-        std::vector<uint8_t> head(n);
-        KVQ_HIP(hipStreamSynchronize(s->stream));
-        KVQ_HIP(hipMemcpy(head.data(), d_data, n, hipMemcpyDeviceToHost));
-        s->tile_bytes = kvq_tile_for_text(head.data(), n, &s->rec_bytes);
-    }
-    const uint32_t TILE = s->tile_bytes;
-    uint64_t nt = 0;
-    for (int64_t c = 0; c < nchunks; c++) {
-        const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
-        nt += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
-    }
-    if (nt == 0) return KVQ_OK;
-    // workgroups per launch: what the CUs hold at once (kvq_scan_bp four per CU, kvq_scan_seeded two)
-    static const uint32_t grid_env = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 0);
-    // (a process that keeps several scan objects is taken to overlap their work -- the next job's scan with the
-    // last one's fold, ordering and copy: one CU in eight then keeps a workgroup slot free, so that those small
-    // kernels run beside the persistent workgroups of the scan instead of behind them; tools: bench.py --pipeline)
-    static const uint32_t cus = kvq_device_cu_count();
-    const uint32_t per_cu = ix->variant ? 2u : 4u;
-    const uint32_t grid_full = cus * per_cu, grid_shared = grid_full - cus / 8u;
-    const uint32_t grid_cap = grid_env ? grid_env : (!ix->variant && kvq_live_scans() > 1) ? grid_shared : grid_full;
-    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 24 + 24576 + KVQ_SKIP_CAP * 16 > s->pool.cap) {       // run_batch made the room
-        kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;
-    }
-    // first tile of every chunk, then the parameter block: one copy
-    const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
-    const size_t ctr_b = 256 + 4 * BP_SHARDS * BP_SHARD_STRIDE;                  // the tile counters (kvq_scan_seeded: one; kvq_scan_bp: BP_SHARDS)
-    const size_t first_at = s->pool.take(first_b + sizeof(BpArgs) + ctr_b);      // ... and the tile counters behind it
-    const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 8), skip_at = s->pool.take(KVQ_SKIP_CAP * 16);      // (report: a word per tile, then a word per tile for the records a skipping tile kept)
-    s->cur_skip_at = skip_at; s->cur_first_at = first_at; s->cur_ntiles = (uint32_t)nt;
-    uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
-    uint64_t acc = 0;
-    for (int64_t c = 0; c < nchunks; c++) {
-        const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
-        first[c] = (uint32_t)acc;
-        acc += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
-    }
-    first[nchunks] = (uint32_t)acc;
-    static const uint32_t dbg = (uint32_t)(getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0);
-    const uint32_t grid_seeded = (uint32_t)std::min<uint64_t>(nt, grid_cap);
-    uint32_t *d_first = reinterpret_cast<uint32_t *>(s->pool.d + first_at);
-    const BpArgs *d_args = reinterpret_cast<const BpArgs *>(s->pool.d + first_at + first_b);
-    const KvqParams *d_params = &d_args->P;
-    uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
-    uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
-    const size_t ctr_at = first_at + first_b + ((sizeof(BpArgs) + 127) & ~(size_t)127);
-    unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + ctr_at);
-    {
-        // the argument block of the scan kernel (kvq_scan_seeded reads its first member, the parameters)
-        BpArgs a;
-        memset(&a, 0, sizeof(a));
-        a.P = P; a.X = ix->dev; a.data = d_data; a.fpos_base = fpos_base;
-        a.tiles = reinterpret_cast<const uint4 *>(d_tchunk); a.tile_report = d_report; a.tile_ctr = d_tile_ctr;
-        a.ntiles = (uint32_t)nt; a.tile_bytes = TILE; a.dbg = dbg;
-        memcpy(s->pool.h + first_at + first_b, &a, sizeof(a));
-    }
-    {
-        unsigned int *hc = reinterpret_cast<unsigned int *>(s->pool.h + ctr_at);
-        memset(hc, 0, 4 * BP_SHARDS * BP_SHARD_STRIDE);
-        if (ix->variant) hc[0] = grid_seeded;                                              // kvq_scan_seeded: tiles below this number are the workgroups' first
-        else for (uint32_t sh = 0; sh < BP_SHARDS; sh++) hc[sh * BP_SHARD_STRIDE] = bp_shard_begin(sh, (uint32_t)nt);
-    }
-    // chunk offsets (run_batch put them right in front), first tiles, arguments, tile counters: one transfer
-    KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, ctr_at + 4 * BP_SHARDS * BP_SHARD_STRIDE - s->cur_co_at,
-                           hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
-
-    typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t, unsigned int *);
-    typedef void (*BpKernel)(const BpArgs *);
-    const int si = ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0, st = (dbg & 16u) ? 3 : 0;
-    if (ix->variant) {
-        static const SeededKernel kernels[6] = { kvq_scan_seeded<2, false>, kvq_scan_seeded<4, false>, kvq_scan_seeded<8, false>,
-                                                 kvq_scan_seeded<2, true>, kvq_scan_seeded<4, true>, kvq_scan_seeded<8, true> };
-        static bool attr_set = false;
-        if (!attr_set) {
-            for (SeededKernel kf : kernels)
-                KVQ_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kernels[si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_params, ix->dev, d_data, fpos_base,
-                           reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg, TILE, d_tile_ctr);
-    } else {
-        // the lane group of a read: four lanes, fixed at compile time, when that is the widest power of two
-        // that gives every read of a full tile its own lanes (records of 100 to 250 bases); otherwise the
-        // kernel that works the width out per tile
-        static const BpKernel kernels[12] = { kvq_scan_bp<2, -1, false>, kvq_scan_bp<4, -1, false>, kvq_scan_bp<8, -1, false>,
-                                              kvq_scan_bp<2, -1, true>, kvq_scan_bp<4, -1, true>, kvq_scan_bp<8, -1, true>,
-                                              kvq_scan_bp<2, 2, false>, kvq_scan_bp<4, 2, false>, kvq_scan_bp<8, 2, false>,
-                                              kvq_scan_bp<2, 2, true>, kvq_scan_bp<4, 2, true>, kvq_scan_bp<8, 2, true> };
-        static const int lg_env = getenv("KVQ_LG") ? atoi(getenv("KVQ_LG")) : -2;
-        int lg = -1;
-        if (s->rec_bytes >= 40u) {
-            const uint32_t n_full = TILE / s->rec_bytes + 1u;                    // records a full tile can own
-            if (n_full <= 128u && n_full > 64u) lg = 2;
-        }
-        if (lg_env >= -1) lg = lg_env == 2 ? 2 : -1;
-        hipLaunchKernelGGL(kernels[(lg == 2 ? 6 : 0) + si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
-    }
-    if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
-    hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
-                       d_first, d_report, s->cur_fail, ix->variant ? (uint4 *)nullptr : reinterpret_cast<uint4 *>(s->pool.d + skip_at));
-    KVQ_HIP(hipGetLastError());
-    if (getenv("KVQ_DBG_REPORT")) {
-        // diagnostic: replay kvq_validate_tiles on the host and name the tiles it rejects
-        KVQ_HIP(hipStreamSynchronize(s->stream));
-        std::vector<uint32_t> rep((size_t)nt);
-        KVQ_HIP(hipMemcpy(rep.data(), d_report, (size_t)nt * 4, hipMemcpyDeviceToHost));
-        for (int64_t c = 0; c < nchunks; c++) {
-            uint32_t seen = 0, total = 0;
-            for (uint32_t g = first[c]; g < first[c + 1]; g++) total += rep[g] & 0xFFFFu;
-            for (uint32_t g = first[c]; g < first[c + 1]; g++) {
-                if (kvq_tile_report_bad(rep[g], g == first[c], seen, total))
-                    fprintf(stderr, "tile %u (chunk %lld [%lld, %lld), tile %u of it): report %08x n_owned %u jn %u seen %u of %u\n",
-                            g, (long long)c, (long long)co[c], (long long)co[c + 1], g - first[c], rep[g], rep[g] & 0xFFFFu, (rep[g] >> 16) & 0xFFu, seen, total);
-                seen += rep[g] & 0xFFFFu;
-            }
-        }
-    }
-    return KVQ_OK;
 }

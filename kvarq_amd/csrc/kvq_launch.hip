@@ -1,0 +1,159 @@
+// kvarq_amd/csrc/kvq_launch.hip -- enqueueing the fused seed-filter scan of one batch (whichever kernel walks the text:
+// kvq_scan_pool by default, kvq_scan_bp with KVQ_KERNEL=v2, kvq_scan_seeded with KVQ_KERNEL=v1)
+#include "kvq_host.h"
+
+// ---------------------------------------------------------------------------
+// launch (both scan kernels)
+// ---------------------------------------------------------------------------
+
+int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, int64_t nbytes,
+                      const uint32_t *d_chunk_off, int64_t nchunks, int64_t fpos_base, uint32_t max_chunk_bytes)
+{
+    (void)nbytes; (void)max_chunk_bytes;
+    SeedIndex *ix = s->t->index;
+    // tiles per chunk; the tables live in the scan's pool so that nothing here waits for the GPU
+    const std::vector<int64_t> &co = s->cur_chunk_off;
+    if (s->tile_bytes == 0) {
+        // first batch of a device-resident scan: look at the head of the text once (the choice is kept
+        // across kvq_scan_reset; host batches are sized on the host, kvq_scan_host_async)
+        const size_t n = (size_t)std::min<int64_t>(nbytes, 128 << 10);
+        std::vector<uint8_t> head(n);
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        KVQ_HIP(hipMemcpy(head.data(), d_data, n, hipMemcpyDeviceToHost));
+        s->tile_bytes = kvq_tile_for_text(head.data(), n, &s->rec_bytes);
+    }
+    const uint32_t TILE = s->tile_bytes;
+    uint64_t nt = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
+        nt += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
+    }
+    if (nt == 0) return KVQ_OK;
+    // workgroups per launch: what the CUs hold at once (kvq_scan_bp four per CU, kvq_scan_seeded two)
+    static const uint32_t grid_env = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 0);
+    // (a process that keeps several scan objects is taken to overlap their work -- the next job's scan with the
+    // last one's fold, ordering and copy: one CU in eight then keeps a workgroup slot free, so that those small
+    // kernels run beside the persistent workgroups of the scan instead of behind them; tools: bench.py --pipeline)
+    static const uint32_t cus = kvq_device_cu_count();
+    const bool v1 = ix->variant == 1;
+    const uint32_t per_cu = v1 ? 2u : 4u;
+    const uint32_t grid_full = cus * per_cu, grid_shared = grid_full - cus / 8u;
+    const uint32_t grid_cap = grid_env ? grid_env : (!v1 && kvq_live_scans() > 1) ? grid_shared : grid_full;
+    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 24 + 24576 + KVQ_SKIP_CAP * 16 > s->pool.cap) {       // run_batch made the room
+        kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;
+    }
+    // first tile of every chunk, then the parameter block: one copy
+    const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
+    const size_t ctr_b = 256 + 4 * BP_SHARDS * BP_SHARD_STRIDE;                  // the tile counters (kvq_scan_seeded: one; kvq_scan_bp: BP_SHARDS)
+    const size_t first_at = s->pool.take(first_b + sizeof(BpArgs) + ctr_b);      // ... and the tile counters behind it
+    const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 8), skip_at = s->pool.take(KVQ_SKIP_CAP * 16);      // (report: a word per tile, then a word per tile for the records a skipping tile kept)
+    s->cur_skip_at = skip_at; s->cur_first_at = first_at; s->cur_ntiles = (uint32_t)nt;
+    uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
+    uint64_t acc = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
+        first[c] = (uint32_t)acc;
+        acc += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
+    }
+    first[nchunks] = (uint32_t)acc;
+    static const uint32_t dbg = (uint32_t)(getenv("KVQ_DBG") ? atoi(getenv("KVQ_DBG")) : 0);
+    const uint32_t grid_seeded = (uint32_t)std::min<uint64_t>(nt, grid_cap);
+    uint32_t *d_first = reinterpret_cast<uint32_t *>(s->pool.d + first_at);
+    const BpArgs *d_args = reinterpret_cast<const BpArgs *>(s->pool.d + first_at + first_b);
+    const KvqParams *d_params = &d_args->P;
+    uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
+    uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
+    const size_t ctr_at = first_at + first_b + ((sizeof(BpArgs) + 127) & ~(size_t)127);
+    unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + ctr_at);
+    {
+        // the argument block of the scan kernel (kvq_scan_seeded reads its first member, the parameters)
+        BpArgs a;
+        memset(&a, 0, sizeof(a));
+        a.P = P; a.X = ix->dev; a.data = d_data; a.fpos_base = fpos_base;
+        a.tiles = reinterpret_cast<const uint4 *>(d_tchunk); a.tile_report = d_report; a.tile_ctr = d_tile_ctr;
+        static const uint32_t stagger = (uint32_t)(getenv("KVQ_STAGGER") ? atoi(getenv("KVQ_STAGGER")) : 0);
+        a.ntiles = (uint32_t)nt; a.tile_bytes = TILE; a.dbg = dbg; a.pad_ = stagger;
+        memcpy(s->pool.h + first_at + first_b, &a, sizeof(a));
+    }
+    {
+        unsigned int *hc = reinterpret_cast<unsigned int *>(s->pool.h + ctr_at);
+        memset(hc, 0, 4 * BP_SHARDS * BP_SHARD_STRIDE);
+        if (v1) hc[0] = grid_seeded;                                              // kvq_scan_seeded: tiles below this number are the workgroups' first
+        else for (uint32_t sh = 0; sh < BP_SHARDS; sh++) hc[sh * BP_SHARD_STRIDE] = bp_shard_begin(sh, (uint32_t)nt);
+    }
+    // chunk offsets (run_batch put them right in front), first tiles, arguments, tile counters: one transfer
+    KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, ctr_at + 4 * BP_SHARDS * BP_SHARD_STRIDE - s->cur_co_at,
+                           hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
+
+    typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t, unsigned int *);
+    typedef void (*BpKernel)(const BpArgs *);
+    const int si = ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0, st = (dbg & 16u) ? 3 : 0;
+    if (v1) {
+        static const SeededKernel kernels[6] = { kvq_scan_seeded<2, false>, kvq_scan_seeded<4, false>, kvq_scan_seeded<8, false>,
+                                                 kvq_scan_seeded<2, true>, kvq_scan_seeded<4, true>, kvq_scan_seeded<8, true> };
+        static bool attr_set = false;
+        if (!attr_set) {
+            for (SeededKernel kf : kernels)
+                KVQ_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kernels[si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_params, ix->dev, d_data, fpos_base,
+                           reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg, TILE, d_tile_ctr);
+    } else {
+        // the lane group of a read: four lanes, fixed at compile time, when that is the widest power of two
+        // that gives every read of a full tile its own lanes (records of 100 to 250 bases); otherwise the
+        // kernel that works the width out per tile
+        static const BpKernel kernels_bp[12] = { kvq_scan_bp<2, -1, false>, kvq_scan_bp<4, -1, false>, kvq_scan_bp<8, -1, false>,
+                                                 kvq_scan_bp<2, -1, true>, kvq_scan_bp<4, -1, true>, kvq_scan_bp<8, -1, true>,
+                                                 kvq_scan_bp<2, 2, false>, kvq_scan_bp<4, 2, false>, kvq_scan_bp<8, 2, false>,
+                                                 kvq_scan_bp<2, 2, true>, kvq_scan_bp<4, 2, true>, kvq_scan_bp<8, 2, true> };
+        static const int lg_env = getenv("KVQ_LG") ? atoi(getenv("KVQ_LG")) : -2;
+        if (ix->variant == 2) {
+            int lg = -1;
+            if (s->rec_bytes >= 40u) {
+                const uint32_t n_full = TILE / s->rec_bytes + 1u;                    // records a full tile can own
+                if (n_full <= 128u && n_full > 64u) lg = 2;
+            }
+            if (lg_env >= -1) lg = lg_env == 2 ? 2 : -1;
+            hipLaunchKernelGGL(kernels_bp[(lg == 2 ? 6 : 0) + si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
+        } else {
+            // kvq_scan_pool: as few lanes per read as leave a lane at most 126 scores (two 63-bit chunks) -- fixed at compile
+            // time (1, 2 or 4 lanes: DPP inside a quad) when the records at the head of the text say so, otherwise
+            // the build that works the width out per tile; [mode][lanes][stride]
+#define PO_ROW(M) { { kvq_scan_pool<2, -1, M>, kvq_scan_pool<4, -1, M>, kvq_scan_pool<8, -1, M> }, { kvq_scan_pool<2, 0, M>, kvq_scan_pool<4, 0, M>, kvq_scan_pool<8, 0, M> }, \
+                  { kvq_scan_pool<2, 1, M>, kvq_scan_pool<4, 1, M>, kvq_scan_pool<8, 1, M> }, { kvq_scan_pool<2, 2, M>, kvq_scan_pool<4, 2, M>, kvq_scan_pool<8, 2, M> } }
+            static const BpKernel kernels_pool[3][4][3] = { PO_ROW(0), PO_ROW(1), PO_ROW(2) };
+#undef PO_ROW
+            int lg = -1;
+            if (s->rec_bytes >= 40u) {
+                const uint32_t q = s->rec_bytes > 25u ? (s->rec_bytes - 25u) / 2u : 1u;   // scores per record, about
+                lg = q <= 120u ? 0 : q <= 240u ? 1 : q <= 480u ? 2 : -1;                    // (a little room: reads vary)
+            }
+            if (lg_env >= -1) lg = lg_env <= 2 ? lg_env : -1;
+            const int mode = (dbg & 16u) ? 2 : dbg ? 1 : 0;
+            hipLaunchKernelGGL(kernels_pool[mode][lg + 1][si], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
+        }
+    }
+    if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
+    hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
+                       d_first, d_report, s->cur_fail, v1 ? (uint4 *)nullptr : reinterpret_cast<uint4 *>(s->pool.d + skip_at));
+    KVQ_HIP(hipGetLastError());
+    if (getenv("KVQ_DBG_REPORT")) {
+        // diagnostic: replay kvq_validate_tiles on the host and name the tiles it rejects
+        KVQ_HIP(hipStreamSynchronize(s->stream));
+        std::vector<uint32_t> rep((size_t)nt);
+        KVQ_HIP(hipMemcpy(rep.data(), d_report, (size_t)nt * 4, hipMemcpyDeviceToHost));
+        for (int64_t c = 0; c < nchunks; c++) {
+            uint32_t seen = 0, total = 0;
+            for (uint32_t g = first[c]; g < first[c + 1]; g++) total += rep[g] & 0xFFFFu;
+            for (uint32_t g = first[c]; g < first[c + 1]; g++) {
+                if (kvq_tile_report_bad(rep[g], g == first[c], seen, total))
+                    fprintf(stderr, "tile %u (chunk %lld [%lld, %lld), tile %u of it): report %08x n_owned %u jn %u seen %u of %u\n",
+                            g, (long long)c, (long long)co[c], (long long)co[c + 1], g - first[c], rep[g], rep[g] & 0xFFFFu, (rep[g] >> 16) & 0xFFu, seen, total);
+                seen += rep[g] & 0xFFFFu;
+            }
+        }
+    }
+    return KVQ_OK;
+}

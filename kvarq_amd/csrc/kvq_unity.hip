@@ -3,6 +3,8 @@
 #include "kernels_general.hip"
 #include "kernels_seeded.hip"
 #include "kernels_bp.hip"
+#include "kernels_pool.hip"
+#include "kvq_launch.hip"
 #include "kernels_results.hip"
 #include "synth.hip"
 #include "kvq_runtime.hip"
