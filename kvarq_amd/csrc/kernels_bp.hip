@@ -235,6 +235,27 @@ __device__ __forceinline__ uint32_t bp_draw(unsigned int *ctr, uint32_t ntiles, 
     }
     return ntiles;
 }
+// the whole wave: the next tile of share `sh` or, when that has run out, of the first share behind it that has tiles left;
+// ntiles when there is none.  All BP_SHARDS counters are looked at with ONE load (lane i reads the counter of share sh + i)
+// and an atomic goes only to a share that still has tiles: when the text runs out a workgroup learns it from one round
+// trip, not from sixty-four atomics one behind the other (which was a fixed 80 us at the end of every launch).
+static_assert(BP_SHARDS == 64u, "one counter per lane of the drawing wave");
+__device__ __forceinline__ uint32_t bp_draw_wave(unsigned int *ctr, uint32_t ntiles, uint32_t &sh, uint32_t lane)
+{
+    for (;;) {
+        const uint32_t mine = (sh + lane) & (BP_SHARDS - 1u);
+        const uint32_t seen = __hip_atomic_load(&ctr[mine * BP_SHARD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t open = __ballot(seen < bp_shard_begin(mine + 1u, ntiles));
+        if (open == 0) return ntiles;
+        const uint32_t pick = (sh + (uint32_t)(__ffsll((long long)open) - 1)) & (BP_SHARDS - 1u);
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&ctr[pick * BP_SHARD_STRIDE], 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        sh = pick;
+        if (t < bp_shard_begin(pick + 1u, ntiles)) return t;
+        // (another workgroup took the share's last tile in between: look again -- every round closes a share for good)
+    }
+}
 typedef const __attribute__((address_space(4))) BpArgs *BpArgsPtr;
 // the block's address, opaque to the compiler from here on: loads through it are issued where they are
 // written, not hoisted to the top of the kernel
@@ -314,6 +335,9 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     const uint32_t wave = rfl((uint32_t)tid >> 6);
     if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t *)lds_raw) != 0u) __builtin_trap();   // lds_u32_at
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_t = 0, wave_p34 = 0;
+    // (instrumented build: the workgroup's life on the constant 100 MHz clock -- entry, end of the prologue, end of its first tile, exit)
+    unsigned long long rt_in = 0, rt_pro = 0, rt_first = 0;
+    if constexpr (STAMPS) rt_in = __builtin_amdgcn_s_memrealtime();
 #define BSTAMP(i) do { if constexpr (STAMPS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
 
     uint32_t ntiles, tile_bytes, dbg, amin;
@@ -323,12 +347,14 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         const GlbWords bm1 = (GlbWords)A->X.bm1;
         for (int i = tid; i < 2048; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = bm1[i];
     }
-    // the drawing lane (first lane of the last wave, which holds the fewest reads) and its share of the tiles
-    uint32_t my_shard = blockIdx.x % BP_SHARDS, shards_left = BP_SHARDS;
-    if (tid == ST_THREADS - 64) {
+    // the drawing wave (the last one, which holds the fewest reads) and its share of the tiles
+    uint32_t my_shard = blockIdx.x % BP_SHARDS; bool no_more = false;
+    if (wave == ST_WAVES - 1u) {
         unsigned int *const ctr = bp_args(A_)->tile_ctr;
-        S.first_tile = bp_draw(ctr, ntiles, my_shard, shards_left);
-        S.next_tile = bp_draw(ctr, ntiles, my_shard, shards_left);
+        const uint32_t t0 = bp_draw_wave(ctr, ntiles, my_shard, (uint32_t)lane);
+        const uint32_t t1 = t0 < ntiles ? bp_draw_wave(ctr, ntiles, my_shard, (uint32_t)lane) : ntiles;
+        no_more = t1 >= ntiles;
+        if (lane == 0) { S.first_tile = t0; S.next_tile = t1; }
     }
     for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) S.hist[i] = 0;
     if (tid == 0) { S.longest_p1 = 0; S.records = 0; S.fallback = 0; }
@@ -347,6 +373,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     // (experiment, KVQ_STAGGER: the workgroups that share a compute unit start a fraction of a tile apart, so that one's wait
     // for its text meets another's arithmetic: workgroup b sits in slot b / 256 of its compute unit under round-robin dispatch)
     if (const uint32_t stg = bp_args(A_)->pad_) { for (uint32_t i = 0; i < (blockIdx.x >> 8) * stg; i++) __builtin_amdgcn_s_sleep(127); }
+    if constexpr (STAMPS) rt_pro = __builtin_amdgcn_s_memrealtime();
     const uint32_t addk = (0x80u - amin) * 0x01010101u;
     uint32_t tiles_done = 0;
     // The barrier that ends a tile stands at the top of the next one, BEHIND the issue of that tile's loads:
@@ -553,7 +580,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                     A->tile_report[g] = (n_owned & 0xFFFFu) | ((jn & 0xFFu) << 16) | (left ? TR_FLAG_SKIPPED : 0u) | (left && nrec ? TR_FLAG_PARTIAL : 0u);
                     if (left) A->tile_report[ntiles + g] = nrec ? g0 - ST_PRE + (uint32_t)S.nl[jn + 4u * nrec - 1u] + 2u : 0u;
                     S.records += nrec;
-                } else if (shards_left) drawn = atomicAdd(&A->tile_ctr[my_shard * BP_SHARD_STRIDE], 1u);
+                } else if (!no_more) drawn = atomicAdd(&A->tile_ctr[my_shard * BP_SHARD_STRIDE], 1u);
             }
         }
 
@@ -837,26 +864,37 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         }
         if constexpr (STAMPS) wave_p34 += __builtin_amdgcn_s_memtime() - wave_t3;
         // everyone is done with the tile's planes before the next tile's fill
-        if (tid == ST_THREADS - 64) {
-            // (the share has run out: on to the next one, now and here -- this happens BP_SHARDS times per workgroup at most)
-            if (!shards_left) drawn = ntiles;
-            else if (drawn >= bp_shard_begin(my_shard + 1u, ntiles)) {
-                my_shard = my_shard + 1u == BP_SHARDS ? 0u : my_shard + 1u; shards_left--;
-                drawn = bp_draw(bp_args(A_)->tile_ctr, ntiles, my_shard, shards_left);
+        if (wave == ST_WAVES - 1u) {
+            // (the tile drawn behind P2 is the first lane's; when the share had run out, the wave looks for another one, now and here)
+            uint32_t d = no_more ? ntiles : rfl(drawn);
+            if (!no_more && d >= bp_shard_begin(my_shard + 1u, ntiles)) {
+                d = bp_draw_wave(bp_args(A_)->tile_ctr, ntiles, my_shard, (uint32_t)tid & 63u);
+                no_more = d >= ntiles;
             }
-            S.next_tile = drawn;
+            if ((tid & 63) == 0) S.next_tile = d;
         }
         KVQ_MARK("tile end");
         BSTAMP(7);
+        if constexpr (STAMPS) { if (rt_first == 0) rt_first = __builtin_amdgcn_s_memrealtime(); }
         g_done = g; g = gn;
     }
 
+    unsigned long long rt_loop = 0;
+    if constexpr (STAMPS) rt_loop = __builtin_amdgcn_s_memrealtime();
     atomicMax(&S.longest_p1, my_longest);
     __syncthreads();
     unsigned long long *const ctr = bp_args(A_)->P.ctr;
     if constexpr (STAMPS) {
         if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
         if (lane == 0) atomicAdd(&ctr[KVQ_CTR_RL_ + 908 + wave], wave_p34);
+        if (tid == 0) {
+            const unsigned long long rt_out = __builtin_amdgcn_s_memrealtime();
+            atomicAdd(&ctr[KVQ_CTR_RL_ + 916], rt_pro - rt_in); atomicAdd(&ctr[KVQ_CTR_RL_ + 917], rt_first ? rt_first - rt_pro : 0ull);
+            atomicAdd(&ctr[KVQ_CTR_RL_ + 918], rt_loop - rt_in); atomicAdd(&ctr[KVQ_CTR_RL_ + 919], 1ull);
+            atomicMax(&ctr[KVQ_CTR_RL_ + 920], rt_out); atomicMax(&ctr[KVQ_CTR_RL_ + 921], rt_in);
+            atomicMax(&ctr[KVQ_CTR_RL_ + 922], ~rt_in);              // ~(earliest entry)
+            atomicAdd(&ctr[KVQ_CTR_RL_ + 923], rt_out - rt_loop);
+        }
     }
     for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) {
         const uint32_t w = S.hist[i];
