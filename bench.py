@@ -148,6 +148,7 @@ def main():
     depth = args.pipeline if args.pipeline > 0 else (3 if len(batches) == 1 else 1)
     ctrs = None
     reduce_by = None
+    join_checked = None
     scanners = []
     if world > 1:
         # the join of the ranks: libkvarq_hip.so's own RCCL communicator (include/kvarq_hip.h, "several GPUs") --
@@ -244,6 +245,20 @@ def main():
         else:                                        # (the library's host copy of the counters is the sum over all ranks)
             total_records = int(r['counters'][_lib.CTR_RECORDS])
             total_hits = int(r['counters'][_lib.CTR_HITS])
+            # the library's sum against an independent one (outside the timed region): every rank's OWN counters of
+            # the last step, summed by torch.distributed, must equal what kvq_scan_finish left on this rank
+            import numpy as np
+            import ctypes as C
+            own = np.zeros(table.counters_len, dtype=np.int64)
+            sc_last = scanners[(args.steps - 1) % depth]
+            assert L_.kvq_memcpy_d2h(own.ctypes.data_as(C.c_void_p), L_.kvq_scan_device_counters_own(sc_last.h), own.nbytes) == 0
+            chk = torch.from_numpy(own).to('cuda')
+            longest = chk[_lib.CTR_LONGEST].clone()
+            dist.all_reduce(chk, op=dist.ReduceOp.SUM); dist.all_reduce(longest, op=dist.ReduceOp.MAX)
+            chk[_lib.CTR_LONGEST] = longest
+            mine = torch.from_numpy(np.array(r['counters'], dtype=np.int64))
+            assert bool((chk.cpu() == mine).all()), 'the library\'s sum over the ranks differs from torch.distributed\'s'
+            join_checked = 'nseqhits, coverage and every other counter of the last step == torch.distributed sum of the ranks\' own counters'
         assert total_records == world * n, 'records lost: %d of %d' % (total_records, world * n)
     else:
         total_records = int(r['counters'][_lib.CTR_RECORDS])

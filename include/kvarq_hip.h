@@ -165,7 +165,8 @@ const int32_t *kvq_scan_hit_readlength(const kvq_scan *s);
 const uint8_t *kvq_scan_hitseq_blob(const kvq_scan *s);       /* workhorse.c:437-439 */
 const int64_t *kvq_scan_hitseq_offsets(const kvq_scan *s);    /* n_hits + 1 */
 const int64_t *kvq_scan_counters(const kvq_scan *s);          /* host copy, kvq_counters_len() */
-void          *kvq_scan_device_counters(const kvq_scan *s);   /* the device array */
+void          *kvq_scan_device_counters(const kvq_scan *s);   /* the device array (several ranks: the sum over all of them once finish has taken it) */
+void          *kvq_scan_device_counters_own(const kvq_scan *s);   /* ... this rank's own counters, whatever finish has summed */
 int64_t        kvq_scan_parsed(const kvq_scan *s);            /* fastq_parsed          */
 int64_t        kvq_scan_total(const kvq_scan *s);             /* fastq_size_estimated  */
 
@@ -194,9 +195,19 @@ void    kvq_scan_force_exhaustive(kvq_scan *s, int32_t on);
  *   kvq_comm_unique_id   rank 0 makes the 128-byte id of a communicator, the caller hands it to the
  *                        other ranks (any way it likes: a file, MPI, torch.distributed ...)
  *   kvq_comm_create      every rank, collectively, with its number and the id; after kvq_set_device
- *   kvq_scan_set_comm    kvq_scan_finish then is collective: behind the rank's own finish the counter
- *                        arrays of all ranks are summed (one all-reduce on the scan's stream; the slot
- *                        of the longest read takes the maximum) on the device and in kvq_scan_counters
+ *   kvq_scan_set_comm    kvq_scan_finish then is collective.  Behind the rank's own finish the ranks
+ *                        agree on how they ended (a maximum over one status word); when all are fine the
+ *                        counter arrays of all ranks are summed (one all-reduce on the scan's stream; the
+ *                        slot of the longest read takes the maximum) into kvq_scan_counters and
+ *                        kvq_scan_device_counters -- the rank's own counters are kept, a second finish
+ *                        sums them afresh.  When ANY rank returns KVQ_ERR_RESCAN (hit arena overflow on
+ *                        host batches) EVERY rank does, with no sum taken: all ranks reset, feed their
+ *                        batches again and finish again, so their collectives stay in step.  Any other
+ *                        failure of one rank is an error on all of them.
+ *   kvq_comm_create_local  instead of kvq_comm_create: the ranks are threads of ONE process (each with a
+ *                        scan of its own, on whatever device it has set) that exchange through host
+ *                        memory -- no RCCL; `world_key` is any number the ranks of one communicator
+ *                        share.  For hosts without RCCL and for testing the join on a single GPU.
  *   kvq_scan_gather_hits after kvq_scan_finish, collective: the hits of all ranks, in rank order --
  *                        ranks scan consecutive stretches of the stream, so that is the reference's
  *                        order -- replace the rank's own behind kvq_scan_n_hits / kvq_scan_hit_* /
@@ -213,6 +224,16 @@ int32_t   kvq_comm_rank(const kvq_comm *c);
 int32_t   kvq_scan_set_comm(kvq_scan *s, kvq_comm *c);
 int32_t   kvq_scan_gather_hits(kvq_scan *s, kvq_comm *c);
 int32_t   kvq_comm_allreduce_counters(kvq_comm *c, void *d_counters, int64_t ctr_len, void *d_scratch16);
+kvq_comm *kvq_comm_create_local(int32_t nranks, int32_t rank, uint64_t world_key);
+/* where kvq_scan_gather_hits puts the ranks' arrays -- a host function of the counts alone (counts[2r] hits,
+ * counts[2r+1] hit bytes of rank r).  parts: 7 x {offset in the rank's own result buffer, offset in the gathered
+ * one, bytes} per rank, in the order file_pos, hitseq offsets, seq_nr, seq_pos, length, readlength, hit bytes;
+ * blob_base[r]: added to rank r's hitseq offsets; totals: {hits, hit bytes, bytes of the gathered buffer, offset
+ * of its hitseq-offset array}.  kvq_gather_host carries the plan out in host memory; kvq_result_layout_words:
+ * the offsets of those seven arrays in a result buffer of n hits and blob_bytes hit bytes, then its size. */
+int32_t   kvq_gather_plan(int32_t nranks, const uint64_t *counts, uint64_t *parts, uint64_t *blob_base, uint64_t *totals);
+int32_t   kvq_gather_host(int32_t nranks, const uint64_t *counts, const uint8_t *const *rank_bufs, uint8_t *out);
+void      kvq_result_layout_words(uint64_t n, uint64_t blob_bytes, uint64_t *out8);
 
 /* ---- engine.findseqs (workhorse.c:1249-1464) -------------------------------
  * files: plain or ".gz" (by suffix, workhorse.c:582), scanned as one stream

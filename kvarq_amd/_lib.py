@@ -62,6 +62,7 @@ PROTOTYPES = {
     'kvq_scan_hitseq_offsets': (P(i64), [vp]),
     'kvq_scan_counters': (P(i64), [vp]),
     'kvq_scan_device_counters': (vp, [vp]),
+    'kvq_scan_device_counters_own': (vp, [vp]),
     'kvq_scan_parsed': (i64, [vp]),
     'kvq_scan_total': (i64, [vp]),
     'kvq_scan_kernel_ms': (C.c_double, [vp]),
@@ -78,6 +79,10 @@ PROTOTYPES = {
     'kvq_scan_set_comm': (i32, [vp, vp]),
     'kvq_scan_gather_hits': (i32, [vp, vp]),
     'kvq_comm_allreduce_counters': (i32, [vp, vp, i64, vp]),
+    'kvq_comm_create_local': (vp, [i32, i32, C.c_uint64]),
+    'kvq_gather_plan': (i32, [i32, vp, vp, vp, vp]),
+    'kvq_gather_host': (i32, [i32, vp, vp, vp]),
+    'kvq_result_layout_words': (None, [C.c_uint64, C.c_uint64, vp]),
     'kvq_findseqs': (vp, [P(cp), i32, P(cp), P(i32), i32]),
     'kvq_findseqs_free': (None, [vp]),
     'kvq_host_chunk_plan': (i64, [P(cp), i32, P(i64), P(i64), i64, P(i64), P(i64), i64]),

@@ -240,14 +240,19 @@ __device__ __forceinline__ uint32_t bp_draw(unsigned int *ctr, uint32_t ntiles, 
 // and an atomic goes only to a share that still has tiles: when the text runs out a workgroup learns it from one round
 // trip, not from sixty-four atomics one behind the other (which was a fixed 80 us at the end of every launch).
 static_assert(BP_SHARDS == 64u, "one counter per lane of the drawing wave");
+// The shares behind `sh` are tried in an order of the workgroup's own (sh + m i for its odd m): with a common order all
+// the workgroups whose shares run out together -- and they do: a grid that is no multiple of 64 leaves half the shares
+// with one workgroup more -- would fall on the same next share, empty it at once and move on as a herd (measured with
+// 992 workgroups: + 11 % kernel time).
 __device__ __forceinline__ uint32_t bp_draw_wave(unsigned int *ctr, uint32_t ntiles, uint32_t &sh, uint32_t lane)
 {
+    const uint32_t m = (((uint32_t)blockIdx.x >> 6) * 2u + 37u) | 1u;
     for (;;) {
-        const uint32_t mine = (sh + lane) & (BP_SHARDS - 1u);
+        const uint32_t mine = (sh + m * lane) & (BP_SHARDS - 1u);
         const uint32_t seen = __hip_atomic_load(&ctr[mine * BP_SHARD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t open = __ballot(seen < bp_shard_begin(mine + 1u, ntiles));
         if (open == 0) return ntiles;
-        const uint32_t pick = (sh + (uint32_t)(__ffsll((long long)open) - 1)) & (BP_SHARDS - 1u);
+        const uint32_t pick = (sh + m * (uint32_t)(__ffsll((long long)open) - 1)) & (BP_SHARDS - 1u);
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(&ctr[pick * BP_SHARD_STRIDE], 1u);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);

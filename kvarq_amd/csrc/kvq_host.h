@@ -74,7 +74,8 @@ struct Batch {
 struct kvq_comm;
 int kvq_live_scans();                 // scan objects alive in this process
 uint32_t kvq_device_cu_count();       // compute units of the current device
-int kvq_comm_reduce_counters(kvq_comm *c, unsigned long long *d_ctr, int64_t ctr_len, unsigned long long *d_scratch, hipStream_t stream);
+int kvq_comm_reduce_counters(kvq_comm *c, const unsigned long long *d_in, unsigned long long *d_out, int64_t ctr_len, unsigned long long *d_scratch, hipStream_t stream);
+int kvq_comm_max_status(kvq_comm *c, unsigned long long mine, unsigned long long *d_scratch, hipStream_t stream, unsigned long long *out);
 
 struct kvq_scan {
     const kvq_table *t = nullptr;
@@ -106,6 +107,7 @@ struct kvq_scan {
     bool host_batches = false;
     int64_t host_pending = -1;           // index of the host batch in flight (kvq_scan_host_async), -1: none
     hipEvent_t ev_copied = nullptr;      // its text has left the host buffer
+    hipEvent_t ev_chain = nullptr;       // this scan's last seed-filter launch is through, kvq_validate_tiles included (what the next scan of the process waits for)
     int64_t records = 0;
     int64_t parsed = 0, total = 0;
     // timing
@@ -121,6 +123,10 @@ struct kvq_scan {
     KvqResultLayout res;                          // where the arrays sit inside pin
     uint64_t n_hits = 0;
     bool finished = false;
+    // several ranks (kvq_dist.hip)
+    DevBuf d_ctr_all;                             // the counters of all ranks, summed (the rank's own stay in d_ctr: a repeated finish sums them afresh)
+    DevBuf d_gather_cnt, d_gather_res;            // kvq_scan_gather_hits: counts of the ranks, the gathered arrays
+    bool reduced = false, gathered = false;
 };
 
 // kernels_seeded.hip

@@ -28,7 +28,10 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
         nt += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
     }
-    if (nt == 0) return KVQ_OK;
+    if (nt == 0) {                      // (nothing to scan: the pair of events of the batch is recorded all the same)
+        if (!s->ev_main.empty()) { KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream)); KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream)); }
+        return KVQ_OK;
+    }
     // workgroups per launch: what the CUs hold at once (kvq_scan_bp four per CU, kvq_scan_seeded two)
     static const uint32_t grid_env = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 0);
     // (a process that keeps several scan objects is taken to overlap their work -- the next job's scan with the
@@ -86,6 +89,10 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
                            hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
 
+    // the scan kernel alone between the pair of events its time is read from (bench.py's roofline figure; rocprofv3 --kernel-trace
+    // gives the same duration): the table upload, kvq_expand_tiles and kvq_validate_tiles stand outside
+    const bool timed = !s->ev_main.empty();
+    if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream));
     typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t, unsigned int *);
     typedef void (*BpKernel)(const BpArgs *);
     const int si = ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0, st = (dbg & 16u) ? 3 : 0;
@@ -135,6 +142,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
             hipLaunchKernelGGL(kernels_pool[mode][lg + 1][si], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
         }
     }
+    if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
     if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                        d_first, d_report, s->cur_fail, v1 ? (uint4 *)nullptr : reinterpret_cast<uint4 *>(s->pool.d + skip_at));

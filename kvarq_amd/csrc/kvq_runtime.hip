@@ -357,7 +357,8 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     if (s->pin) (void)hipHostFree(s->pin);
     if (s->pin_small) (void)hipHostFree(s->pin_small);
     if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
-    DevBuf *bufs[] = { &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_order, &s->d_finish, &s->d_covdiff, &s->d_skipped, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
+    if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
+    DevBuf *bufs[] = { &s->d_ctr_all, &s->d_gather_cnt, &s->d_gather_res, &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_order, &s->d_finish, &s->d_covdiff, &s->d_skipped, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
                        &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
     for (DevBuf *b : bufs) b->release();
     s->pool.release();
@@ -375,7 +376,7 @@ extern "C" int32_t kvq_scan_reset(kvq_scan *s)
     KVQ_HIP(hipStreamSynchronize(s->stream));
     drop_events(s);
     s->batches.clear(); s->host_batches = false; s->host_pending = -1; s->records = 0; s->parsed = 0; s->total = 0;
-    s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->path_bits = 0; s->n_hits = 0;
+    s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->reduced = false; s->gathered = false; s->path_bits = 0; s->n_hits = 0;
     s->pool.used = 0;
     const int rr = reset_device_state(s);
     if (g_timing) fprintf(stderr, "reset host %.3f ms\n", now_ms() - tr0);
@@ -463,14 +464,14 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     if (use_seeded) {
         if ((rc = new_event_pair(s, s->ev_main))) return rc;
         if ((rc = chain_wait(s))) return rc;
-        KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream));
-        KvqParams PS = P;                          // counters and error of this batch are staged until it is validated
+        KvqParams PS = P;                          // counters and error of this batch are staged until it is validated (the pair of events is recorded right around the scan kernel: kvq_seeded_launch)
         PS.ctr = s->d_stage_ctr; PS.err = s->d_err_stage;
         s->cur_fail = s->d_fail + batch_no;
         if ((rc = kvq_seeded_launch(s, PS, d_data, nbytes, d_co, nchunks, fpos_base, maxchunk))) return rc;
         s->batches[batch_no].skip_at = s->cur_skip_at; s->batches[batch_no].tile_bytes = s->tile_bytes;
-        KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
-        chain_publish(s, s->ev_main.back().second);
+        if (!s->ev_chain) KVQ_HIP(hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming));
+        KVQ_HIP(hipEventRecord(s->ev_chain, s->stream));
+        chain_publish(s, s->ev_chain);
         s->main_launches++; s->path_bits |= 1;
         hist_done = true;
     }
@@ -883,18 +884,36 @@ int kvq_scan_finish_internal(kvq_scan *s)
     return KVQ_ERR_MEMORY;
 }
 
-// several GPUs (kvq_scan_set_comm): the counters of all ranks summed over RCCL, on the device and in the host
-// copy.  `finish` is collective then: a rank whose own scan has failed still takes part, so that the others
-// do not wait for it for ever, and reports its error afterwards.
-static int reduce_over_ranks(kvq_scan *s)
+// several GPUs (kvq_scan_set_comm): `finish` is collective.  First the ranks agree on how their own scans
+// ended -- the maximum of 0 (fine), 1 (this rank has to be fed its host batches again) and 2 (failed): only when
+// every rank is fine are the counters of all ranks summed (into an array of their own: the rank's counters stay
+// what they are, so that finishing twice does not sum sums); when some rank has to go round again every rank
+// returns KVQ_ERR_RESCAN and goes round with it, with no sum taken (the collectives of the ranks stay in step);
+// a failure anywhere is an error everywhere.
+static int finish_over_ranks(kvq_scan *s, int rc_own)
 {
     int rc;
     if ((rc = s->d_finish.ensure(sizeof(KvqFinishState) + 256))) return rc;
     unsigned long long *scratch = (unsigned long long *)((char *)s->d_finish.p + ((sizeof(KvqFinishState) + 15) & ~(size_t)15));
-    if ((rc = kvq_comm_reduce_counters(s->comm, s->d_ctr, s->t->ctr_len, scratch, s->stream))) return rc;
-    KVQ_HIP(hipMemcpyAsync(s->pin, s->d_ctr, (size_t)s->t->ctr_len * 8, hipMemcpyDeviceToHost, s->stream));
+    unsigned long long worst = 0;
+    const unsigned long long mine = rc_own == KVQ_OK ? 0ull : rc_own == KVQ_ERR_RESCAN ? 1ull : 2ull;
+    if ((rc = kvq_comm_max_status(s->comm, mine, scratch, s->stream, &worst))) return rc;
+    if (worst == 2) {
+        if (rc_own != KVQ_OK && rc_own != KVQ_ERR_RESCAN) return rc_own;             // (its own message stands)
+        kvq_set_error(KVQ_ERR_RUNTIME, "the scan of another rank has failed");
+        return KVQ_ERR_RUNTIME;
+    }
+    if (worst == 1) {
+        if (rc_own != KVQ_ERR_RESCAN) kvq_set_error(KVQ_ERR_RESCAN, "the hit arena of another rank overflowed on host batches: every rank resets its scan and feeds its batches again");
+        s->finished = false;
+        return KVQ_ERR_RESCAN;
+    }
+    if ((rc = s->d_ctr_all.ensure((size_t)s->t->ctr_len * 8))) return rc;
+    if ((rc = kvq_comm_reduce_counters(s->comm, s->d_ctr, s->d_ctr_all.as<unsigned long long>(), s->t->ctr_len, scratch, s->stream))) return rc;
+    KVQ_HIP(hipMemcpyAsync(s->pin, s->d_ctr_all.p, (size_t)s->t->ctr_len * 8, hipMemcpyDeviceToHost, s->stream));
     KVQ_HIP(hipStreamSynchronize(s->stream));
     memcpy(s->h_ctr.data(), s->pin, (size_t)s->t->ctr_len * 8);
+    s->reduced = true;
     return KVQ_OK;
 }
 
@@ -905,8 +924,9 @@ extern "C" int32_t kvq_scan_finish(kvq_scan *s)
     if (rc == KVQ_NEED_RESCAN) { kvq_set_error(KVQ_ERR_RESCAN, "hit arena overflow on host batches: the arena has been enlarged, reset the scan and feed the batches again"); rc = KVQ_ERR_RESCAN; }
     if (s->comm) {
         const int saved = kvq_error_code(); char msg[1024]; kvq_last_error(msg, sizeof(msg));
-        const int rc2 = reduce_over_ranks(s);
-        if (rc) kvq_set_error(saved, "%s", msg); else rc = rc2;
+        const int rc2 = finish_over_ranks(s, rc);
+        if (rc && rc2 == rc) kvq_set_error(saved, "%s", msg);
+        rc = rc2;
     }
     return rc;
 }
@@ -920,7 +940,8 @@ extern "C" const int32_t *kvq_scan_hit_readlength(const kvq_scan *s) { return re
 extern "C" const uint8_t *kvq_scan_hitseq_blob(const kvq_scan *s) { return s->pin_res + s->res.blob; }
 extern "C" const int64_t *kvq_scan_hitseq_offsets(const kvq_scan *s) { return reinterpret_cast<const int64_t *>(s->pin_res + s->res.hitseq_off); }
 extern "C" const int64_t *kvq_scan_counters(const kvq_scan *s) { return s->h_ctr.data(); }
-extern "C" void *kvq_scan_device_counters(const kvq_scan *s) { return s->d_ctr; }
+extern "C" void *kvq_scan_device_counters(const kvq_scan *s) { return s->reduced ? s->d_ctr_all.p : (void *)s->d_ctr; }
+extern "C" void *kvq_scan_device_counters_own(const kvq_scan *s) { return s->d_ctr; }
 extern "C" int64_t kvq_scan_parsed(const kvq_scan *s) { return s->parsed; }
 extern "C" int64_t kvq_scan_total(const kvq_scan *s) { return s->total; }
 extern "C" double kvq_scan_kernel_ms(const kvq_scan *s) { return s->ms_all; }

@@ -47,6 +47,24 @@ class NativeComm(object):
             self.h = None
 
 
+class LocalComm(object):
+    """the loopback communicator of libkvarq_hip.so (``kvq_comm_create_local``): the ranks are threads of this one
+    process, each with a ``Scanner`` of its own, and exchange through host memory.  `key`: any number the ranks of
+    one communicator share.  The join code behind it is the one RCCL communicators use -- this is how it runs with
+    more than one rank on a box with a single GPU."""
+
+    def __init__(self, world, rank, key):
+        self.h = _lib.lib().kvq_comm_create_local(world, rank, key)
+        if not self.h:
+            raise RuntimeError(_lib.last_error()[1])
+        self.world, self.rank = world, rank
+
+    def close(self):
+        if self.h:
+            _lib.lib().kvq_comm_destroy(self.h)
+            self.h = None
+
+
 def shard(n_items, rank, world):
     """contiguous share [begin, end) of n_items for `rank`; shares differ by at most one item"""
     base, extra = divmod(n_items, world)

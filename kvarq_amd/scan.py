@@ -83,15 +83,26 @@ def _view(ptr, n, ctype, dtype):
     return np.frombuffer((ctype * n).from_address(addr), dtype=dtype)
 
 
-class Scanner(object):
-    """accumulates hits and counters over any number of batches"""
+class RescanRequired(RuntimeError):
+    """the hit arena overflowed on host batches that the Scanner no longer holds: reset() and feed them again"""
 
-    def __init__(self, table, counters_ptr=None):
+
+class Scanner(object):
+    """accumulates hits and counters over any number of batches.
+
+    Host batches (``scan_host``) cannot be replayed by the library when the hit arena turns out too small
+    (``KVQ_ERR_RESCAN``); ``finish`` feeds them again itself from COPIES it keeps -- up to `retain_limit` bytes
+    (the caller's buffers are never kept: they may be refilled).  Beyond that limit, or with ``retain_limit=0``,
+    ``finish`` raises ``RescanRequired`` and the caller, who has the data, resets and feeds again; a caller with
+    a re-readable source passes ``replay=callable`` (called with the scanner after ``reset()``) instead."""
+
+    def __init__(self, table, counters_ptr=None, retain_limit=1 << 30, replay=None):
         self.table = table
         self.h = _lib.lib().kvq_scan_create(table.h, counters_ptr)
         if not self.h:
             _raise_last()
-        self._host_batches = []          # what scan_host was given since the last reset (fed again when the hit arena overflows)
+        self._host_batches = []          # copies of what scan_host was given since the last reset (fed again when the hit arena overflows)
+        self._retained, self._retain_limit, self._replay = 0, (0 if replay is not None else retain_limit), replay
         self._comm = None
 
     def set_comm(self, comm):
@@ -115,7 +126,11 @@ class Scanner(object):
     def scan_host(self, data, chunk_off=None, fpos_base=0):
         arr = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         co = chunk_offsets(arr) if chunk_off is None else np.ascontiguousarray(chunk_off, dtype=np.int64)
-        self._host_batches.append((arr, co, fpos_base))
+        if self._host_batches is not None:
+            if self._retained + arr.nbytes <= self._retain_limit:
+                self._host_batches.append((arr.copy(), co.copy(), fpos_base)); self._retained += arr.nbytes
+            else:
+                self._host_batches = None          # too much to keep: an overflow is the caller's to replay
         _check(_lib.lib().kvq_scan_host(self.h, arr.ctypes.data if arr.nbytes else None, arr.nbytes,
                                         co.ctypes.data_as(C.POINTER(C.c_int64)), len(co) - 1, fpos_base))
 
@@ -132,10 +147,15 @@ class Scanner(object):
             if _lib.last_error()[0] != _lib.ERR_RESCAN or attempt == 3:
                 _raise_last()
             # the hit arena was too small for the host batches (it has been enlarged): feed them again
-            again = self._host_batches
+            again, replay = self._host_batches, self._replay
+            if again is None and replay is None:
+                raise RescanRequired(_lib.last_error()[1])
             self.reset()
-            for arr, co, fpos_base in again:
-                self.scan_host(arr, co, fpos_base)
+            if replay is not None:
+                replay(self)
+            else:
+                for arr, co, fpos_base in again:
+                    self.scan_host(arr, co, fpos_base)
         t = self.table
         ctr = _view(L.kvq_scan_counters(self.h), t.counters_len, C.c_int64, np.int64)
         if stats:

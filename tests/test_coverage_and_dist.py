@@ -134,3 +134,58 @@ def test_two_rank_reduction_equals_single_scan(tmp_path):
     assert ctr[o + 2 * nseq + bases:].tolist() == whole['mutations']
     assert [tuple(h) for h in got['hits']] == [tuple(h) for h in whole['hits']]
     assert [x if isinstance(x, bytes) else x.encode('latin-1') for x in got['hitseqs']] == [x if isinstance(x, bytes) else x.encode('latin-1') for x in whole['hitseqs']]
+
+
+# ---- the native join (kvarq_amd/csrc/kvq_dist.hip): where the ranks' arrays go, on the CPU -------------------
+
+def _rank_buffer(L, hits, hitseqs):
+    """one rank's result buffer as kvq_scan_finish lays it out (kvq_result_layout_words)"""
+    import ctypes as C
+    n, blob = len(hits), b''.join(hitseqs)
+    w = (C.c_uint64 * 8)()
+    L.kvq_result_layout_words(n, len(blob), w)
+    buf = np.zeros(int(w[7]) + 16, dtype=np.uint8)
+    def put(at, arr):
+        raw = np.ascontiguousarray(arr).view(np.uint8)
+        buf[at:at + raw.size] = raw
+    put(int(w[0]), np.array([h[1] for h in hits], dtype=np.int64))
+    put(int(w[1]), np.cumsum([0] + [len(x) for x in hitseqs]).astype(np.int64))
+    put(int(w[2]), np.array([h[0] for h in hits], dtype=np.int32)); put(int(w[3]), np.array([h[2] for h in hits], dtype=np.int32))
+    put(int(w[4]), np.array([h[3] for h in hits], dtype=np.int32)); put(int(w[5]), np.array([h[4] for h in hits], dtype=np.int32))
+    put(int(w[6]), np.frombuffer(blob, dtype=np.uint8))
+    return buf, len(blob)
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_gather_plan_puts_every_ranks_arrays_in_stream_order(world):
+    """kvq_gather_plan / kvq_gather_host (the arithmetic of kvq_scan_gather_hits, without a GPU): the oracle's single
+    scan, cut into the ranks' shares by dist.shard -- uneven ones, and ranks without a hit -- comes back whole"""
+    import ctypes as C
+    L = _lib.lib()
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g))
+    nreads, rb = 3000, synth.record_bytes(150)
+    whole = O.scan_memory(synth.reads(g, 0, nreads, 150), seqs, nthreads=4, **cases.PRODUCT)
+    hits = [tuple(h) for h in whole['hits']]
+    hs = [x if isinstance(x, bytes) else x.encode('latin-1') for x in whole['hitseqs']]
+    # shares of very different sizes: rank 1 gets (nearly) nothing when there are more than two ranks
+    cuts = [0] + [kdist.shard(nreads, r, world)[1] for r in range(world)]
+    if world > 2:
+        cuts[2] = cuts[1] + 1
+    bufs, counts = [], []
+    for r in range(world):
+        lo, hi = cuts[r] * rb, cuts[r + 1] * rb
+        idx = [i for i, h in enumerate(hits) if lo <= h[1] < hi]
+        b, nb = _rank_buffer(L, [hits[i] for i in idx], [hs[i] for i in idx])
+        bufs.append(b); counts += [len(idx), nb]
+    assert sum(counts[0::2]) == len(hits) and (world == 2 or min(counts[0::2]) == 0 or counts[2] <= 1)
+    cnt = (C.c_uint64 * (2 * world))(*counts)
+    parts = (C.c_uint64 * (21 * world))(); base = (C.c_uint64 * world)(); tot = (C.c_uint64 * 4)()
+    assert L.kvq_gather_plan(world, cnt, parts, base, tot) == 0
+    assert tot[0] == len(hits) and tot[1] == sum(len(x) for x in hs)
+    assert list(base) == list(np.cumsum([0] + counts[1::2])[:-1])
+    out = np.zeros(int(tot[2]) + 16, dtype=np.uint8)
+    ptrs = (C.c_void_p * world)(*[b.ctypes.data for b in bufs])
+    assert L.kvq_gather_host(world, cnt, ptrs, out.ctypes.data) == 0
+    want, _ = _rank_buffer(L, hits, hs)
+    assert out[:int(tot[2])].tobytes() == want[:int(tot[2])].tobytes()

@@ -493,6 +493,107 @@ def test_native_rccl_communicator_of_one_rank():
     s.set_comm(None)
     s.close(); t.close(); comm.close()
 
+def _ranks_in_threads(world, work):
+    """`work(rank, comm)` on `world` threads of this process, each with a loopback communicator of its own
+    (kvq_comm_create_local): the library's join code with several ranks on the one GPU there is"""
+    import threading
+    from kvarq_amd import dist as kdist
+    key = int.from_bytes(os.urandom(7), 'little')
+    out, err = [None] * world, [None] * world
+    def run(r):
+        comm = None
+        try:
+            comm = kdist.LocalComm(world, r, key)
+            out[r] = work(r, comm)
+        except BaseException as e:                                  # noqa: a failure of one rank must not leave the others waiting unnoticed
+            err[r] = e
+        finally:
+            if comm is not None:
+                comm.close()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(300)
+    assert not any(x.is_alive() for x in th), 'a rank is stuck in a collective'
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_native_join_of_several_ranks_equals_one_scan(world):
+    """kvq_scan_finish + kvq_scan_gather_hits with MORE THAN ONE rank (workhorse.c:1398-1447): the ranks are threads
+    with a scan each, their communicator the library's loopback -- counters summed, longest read the maximum,
+    hits of all ranks in stream order on every rank, equal to the oracle's single scan; finishing twice gives
+    the same sums (the ranks' own counters are not overwritten)"""
+    from kvarq_amd import dist as kdist
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g))
+    nreads, rb = 9000, synth.record_bytes(150)
+    host = synth.reads(g, 0, nreads, 150)
+    whole = O.scan_memory(host, seqs, fold=True, nthreads=4, **cases.PRODUCT)
+    t = scan.Table(seqs, **cases.PRODUCT)
+    def work(rank, comm):
+        lo, hi = kdist.shard(nreads, rank, world)
+        if world == 3 and rank == 1:
+            hi = lo                                                   # a rank without a single read
+        if world == 3 and rank == 2:
+            lo = kdist.shard(nreads, 1, world)[0]
+        s = scan.Scanner(t)
+        s.set_comm(comm)
+        s.scan_host(host[lo * rb:hi * rb], fpos_base=lo * rb)
+        r = s.finish(hits=False)
+        again = s.finish(hits=False)                                  # (collective too: every rank does it)
+        assert again['counters'].tolist() == r['counters'].tolist()
+        got = s.gather_hits()
+        got2 = s.gather_hits()                                        # a second call finds the gathered arrays in place
+        assert got2['n_hits'] == got['n_hits']
+        res = dict(counters=r['counters'].copy(), hits=[tuple(h) for h in got['hits']], hitseqs=[bytes(x) for x in got['hitseqs']], stats=r['stats'],
+                   coverage=r['coverage'].tolist(), mutations=r['mutations'].tolist())
+        s.set_comm(None); s.close()
+        return res
+    outs = _ranks_in_threads(world, work)
+    for o in outs:
+        assert o['hits'] == [tuple(h) for h in whole['hits']]
+        assert o['hitseqs'] == [x if isinstance(x, bytes) else x.encode('latin-1') for x in whole['hitseqs']]
+        assert o['stats']['records_parsed'] == nreads and o['stats']['nseqhits'] == whole['stats']['nseqhits']
+        assert o['stats']['nseqbasehits'] == whole['stats']['nseqbasehits'] and o['stats']['readlengths'] == whole['stats']['readlengths']
+        assert o['coverage'] == whole['coverage'] and o['mutations'] == whole['mutations']
+    t.close()
+
+
+def test_arena_overflow_on_one_rank_takes_every_rank_round_again():
+    """rank 1's host batches overflow its hit arena (KVQ_ERR_RESCAN), rank 0's do not: BOTH ranks are told to go round
+    again, no partial sum is taken, their collectives stay in step, and the second round gives the right totals"""
+    read = 'ACG' * 60
+    rec_hits = cases.rec('x', read, 'I' * len(read))
+    rec_none = cases.rec('x', 'T' * len(read), 'I' * len(read))
+    shares = [rec_none * 20000 + rec_hits * 10, rec_hits * 40000]          # 600 hits / 2.4 M hits (the arena starts at 1 M)
+    t = scan.Table([b'ACG'], **dict(cases.DEFAULTS, minreadlength=10))
+    def work(rank, comm):
+        s = scan.Scanner(t, retain_limit=0)                                # (the caller replays: it sees the KVQ_ERR_RESCAN of the other rank)
+        s.set_comm(comm)
+        rounds = 0
+        while True:
+            rounds += 1
+            s.scan_host(np.frombuffer(shares[rank], dtype=np.uint8), fpos_base=0 if rank == 0 else len(shares[0]))
+            try:
+                r = s.finish(hits=False)
+                break
+            except scan.RescanRequired:
+                s.reset()
+        n = int(r['counters'][t.off_nseqhits])
+        own = int(r['n_hits'])
+        s.set_comm(None); s.close()
+        return rounds, n, own, int(r['counters'][_lib.CTR_RECORDS])
+    outs = _ranks_in_threads(2, work)
+    assert [o[0] for o in outs] == [2, 2]
+    assert [o[1] for o in outs] == [600 + 40000 * 60] * 2 and [o[2] for o in outs] == [600, 40000 * 60]
+    assert [o[3] for o in outs] == [60010] * 2
+    t.close()
+
 
 def test_one_long_record_costs_its_tile_not_the_batch():
     """300 k ordinary reads with ONE 5 kB record in their middle: the record outgrows the look-ahead of the tile
