@@ -129,28 +129,46 @@ kvq_index_records(const uint8_t *__restrict__ data, const uint32_t *__restrict__
 // lie (a record may run to the end of the chunk).  nl4 / rec_start as kvq_index_records writes them.
 struct KvqSkippedTile { uint32_t a, b, own_begin, own_end, seen, first; };
 
+// How many items a kernel has to deal with, when that number is only known on the device (the redo of skipped tiles is
+// enqueued behind every seed-filter launch, without the host looking: kvq_runtime.hip): `n` when d_n is null, else
+// *d_n >> shift -- nothing when the batch's fail word says the whole batch is redone anyway (bit 0), and a number beyond
+// `cap` (the tables are full) raises that bit, so that the batch IS redone as a whole.  The kernels walk their items with a
+// stride of their grid: a launch of fixed size serves any count.
+struct KvqDevCount { const unsigned int *d_n; unsigned int shift, cap; unsigned int *fail; };
+__device__ __forceinline__ uint32_t kvq_dev_count(uint32_t n, const KvqDevCount &c)
+{
+    if (!c.d_n) return n;
+    if (c.fail && (*c.fail & 1u)) return 0u;
+    const uint32_t v = *c.d_n >> c.shift;
+    if (v > c.cap) { if (c.fail && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) atomicOr(c.fail, 1u); return 0u; }
+    return v;
+}
+
 extern "C" __global__ void __launch_bounds__(256)
-kvq_collect_skipped(const uint8_t *__restrict__ data, const KvqSkippedTile *__restrict__ tiles, uint32_t ntiles,
+kvq_collect_skipped(const uint8_t *__restrict__ data, const KvqSkippedTile *__restrict__ tiles, uint32_t ntiles_, KvqDevCount dc,
                     uint32_t *__restrict__ nl4, uint32_t *__restrict__ rec_start, unsigned int *__restrict__ rec_count, uint32_t rec_cap)
 {
-    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (w >= ntiles) return;
+    const uint32_t ntiles = kvq_dev_count(ntiles_, dc);
     const int lane = kvq_lane();
+    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < ntiles; w += gridDim.x * 4u) {
     const KvqSkippedTile T = tiles[w];
     uint32_t idx = T.seen;                       // number (within the chunk) of the next newline met
     bool collecting = T.first != 0u;             // tile 0: the chunk's first record
     uint32_t rstart = T.a, cnt = 0, nlb[4] = { 0, 0, 0, 0 };
-    for (uint32_t p4 = T.own_begin; p4 < T.b; p4 += 256u) {
+    for (uint32_t p4 = T.own_begin; p4 < T.b; p4 += 1024u) {
         if (p4 >= T.own_end && !collecting) break;
-        // (four loads in flight: a record of thousands of bytes is a chain of memory round trips otherwise)
-        bool nl[4];
+        // (sixteen loads in flight: a record of thousands of bytes is a chain of memory round trips otherwise)
+        // (every load is issued whatever its place: a load behind a branch is waited for before the next one goes out)
+        uint8_t by[16]; bool nl[16];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 16; k++) {
             const uint32_t q = p4 + 64u * (uint32_t)k + (uint32_t)lane;
-            nl[k] = q < T.b && data[q] == '\n';
+            by[k] = data[q < T.b ? q : T.b - 1u];
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 16; k++) nl[k] = p4 + 64u * (uint32_t)k + (uint32_t)lane < T.b && by[k] == '\n';
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
             const uint32_t p = p4 + 64u * (uint32_t)k;
             if (p >= T.b || (p >= T.own_end && !collecting)) break;
             unsigned long long m = __ballot(nl[k]);
@@ -170,6 +188,7 @@ kvq_collect_skipped(const uint8_t *__restrict__ data, const KvqSkippedTile *__re
                 idx++;
             }
         }
+    }
     }
 }
 
@@ -211,21 +230,25 @@ __device__ __forceinline__ void run_feed(RunState &st, uint64_t good, int nbits,
 // read_off[g] = batch offset of the first base of the trimmed read,
 // read_len[g] = its length, or -1 when shorter than minreadlength (workhorse.c:1100)
 extern "C" __global__ void __launch_bounds__(256)
-kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, uint32_t nrec,
+kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, uint32_t nrec_, KvqDevCount dc,
                  const uint32_t *__restrict__ nl4, const uint32_t *__restrict__ rec_start,
                  uint32_t *__restrict__ read_off, int32_t *__restrict__ read_len, int32_t count, uint32_t rpw)
 {
+    const uint32_t nrec = kvq_dev_count(nrec_, dc);
+    if (nrec == 0) return;
     // rpw: consecutive records per wave (KVQ_TRIM_RPW for a batch of ordinary reads; 1 for the few, possibly very
     // long records of skipped tiles)
     __shared__ unsigned int hist[KVQ_RL_BINS];
     __shared__ int longest;
+    __shared__ unsigned int nproc;
     for (int i = threadIdx.x; i < KVQ_RL_BINS; i += blockDim.x) hist[i] = 0;
-    if (threadIdx.x == 0) longest = -1;
+    if (threadIdx.x == 0) { longest = -1; nproc = 0; }
     __syncthreads();
 
     const int lane = kvq_lane();
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    for (uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6); (uint64_t)wave * rpw < nrec; wave += gridDim.x * 4u) {
     const uint32_t g_begin = wave * rpw;
+    if (lane == 0) atomicAdd(&nproc, nrec - g_begin < rpw ? nrec - g_begin : rpw);
     for (uint32_t g = g_begin; g < g_begin + rpw && g < nrec; g++) {
         const uint32_t rstart = rec_start[g];
         const uint32_t n0 = nl4[4 * (size_t)g], n1 = nl4[4 * (size_t)g + 1], n2 = nl4[4 * (size_t)g + 2], n3 = nl4[4 * (size_t)g + 3];
@@ -240,16 +263,19 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
         // score line including its '\n': bytes [sscore, n3]
         const uint32_t qlen = n3 - sscore + 1u;
         RunState st; st.in_run = 1; st.run_start = 0; st.best = 0; st.best_start = 0;   // qtr starts at startscore (1055)
-        for (uint32_t o4 = 0; o4 < qlen; o4 += 256u) {
-            // (four loads in flight: a score line of thousands of bytes is a chain of memory round trips otherwise)
-            bool ok[4];
+        for (uint32_t o4 = 0; o4 < qlen; o4 += 1024u) {
+            // (sixteen loads in flight: a score line of thousands of bytes is a chain of memory round trips otherwise;
+            // ordinary reads are done with the first few)
+            uint8_t by[16]; bool ok[16];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 16; k++) {
                 const uint32_t i = o4 + 64u * (uint32_t)k + (uint32_t)lane;
-                ok[k] = (i < qlen) && ((int)(int8_t)data[sscore + i] >= P.amin);
+                by[k] = data[sscore + (i < qlen ? i : qlen - 1u)];                 // (unconditional loads travel together; qlen >= 1: the closing newline)
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 16; k++) ok[k] = (o4 + 64u * (uint32_t)k + (uint32_t)lane < qlen) && ((int)(int8_t)by[k] >= P.amin);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
                 const uint32_t o = o4 + 64u * (uint32_t)k;
                 if (o >= qlen) break;
                 const uint64_t good = __ballot(ok[k]);
@@ -267,6 +293,7 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
             read_len[g] = rl >= P.minreadlength ? rl : -1;
         }
     }
+    }
     __syncthreads();
     if (!count) return;
     for (int i = threadIdx.x; i < KVQ_RL_BINS; i += blockDim.x)
@@ -274,9 +301,7 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
     if (threadIdx.x == 0) {
         if (longest >= 0) atomicMax(&P.ctr[KVQ_CTR_LONGEST_], (unsigned long long)(longest + 1));
         // records of this block (add_records_parsed, 1187)
-        const uint32_t first = blockIdx.x * 4u * rpw;
-        const uint32_t n = nrec > first ? (nrec - first < 4u * rpw ? nrec - first : 4u * rpw) : 0u;
-        if (n) atomicAdd(&P.ctr[KVQ_CTR_RECORDS_], (unsigned long long)n);
+        if (nproc) atomicAdd(&P.ctr[KVQ_CTR_RECORDS_], (unsigned long long)nproc);
     }
 }
 
@@ -287,8 +312,16 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
 // mismatches of x[0..n) vs y[0..n) stay within the budget?
 __device__ __forceinline__ bool within_budget(const uint8_t *x, const uint8_t *y, int n, int budget)
 {
-    int e = 0;
-    for (int j = 0; j < n; j++) {
+    int e = 0, j = 0;
+    // four bytes at a time (any alignment), two such pairs of loads in flight: most alignments are over after the first
+    for (; j + 8 <= n; j += 8) {
+        uint32_t a0, a1, b0, b1;
+        __builtin_memcpy(&a0, x + j, 4); __builtin_memcpy(&a1, x + j + 4, 4); __builtin_memcpy(&b0, y + j, 4); __builtin_memcpy(&b1, y + j + 4, 4);
+        const uint32_t v0 = a0 ^ b0, v1 = a1 ^ b1;
+        e += __popc((((v0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v0) & 0x80808080u) + __popc((((v1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v1) & 0x80808080u);
+        if (e > budget) return false;
+    }
+    for (; j < n; j++) {
         e += (x[j] != y[j]);
         if (e > budget) return false;
     }
@@ -298,15 +331,15 @@ __device__ __forceinline__ bool within_budget(const uint8_t *x, const uint8_t *y
 // one wave per read; lanes share out the alignments ("jobs") of the read
 // against one sequence: class A jobs, then class B, then class C.
 extern "C" __global__ void __launch_bounds__(256)
-kvq_match_all(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, uint32_t nrec,
+kvq_match_all(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, uint32_t nrec_, KvqDevCount dc,
               const uint32_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
               const int32_t *__restrict__ seq_list, int32_t nlist)
 {
     const int lane = kvq_lane();
-    const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (g >= nrec) return;
+    const uint32_t nrec = kvq_dev_count(nrec_, dc);
+    for (uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6); g < nrec; g += gridDim.x * 4u) {
     const int rl = read_len[g];
-    if (rl < 0) return;
+    if (rl < 0) continue;
     const uint8_t *read = data + read_off[g];
     const int64_t fpos = fpos_base + read_off[g];
     const int mo = P.minoverlap, me = P.maxerrors;
@@ -348,6 +381,7 @@ kvq_match_all(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, 
             }
             kvq_emit(P, hit, fpos, s, spos, len, rl, key);
         }
+    }
     }
 }
 

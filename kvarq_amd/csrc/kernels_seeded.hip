@@ -1117,10 +1117,12 @@ __host__ __device__ static inline bool kvq_tile_report_bad(uint32_t rep, bool fi
 
 extern "C" __global__ void __launch_bounds__(256)
 kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_report,
-                   unsigned int *__restrict__ spec_fail, uint4 *__restrict__ skip_list)
+                   unsigned int *__restrict__ spec_fail, KvqSkippedTile *__restrict__ skip_list,
+                   const uint32_t *__restrict__ chunk_off, uint32_t tile_bytes)
 {
-    // *spec_fail: bit 0 = the batch failed; from bit 8 on = number of skipped tiles (their numbers, the
-    // newlines of their chunk in front of them and the records they did take go to skip_list)
+    // *spec_fail: bit 0 = the batch failed; from bit 8 on = number of skipped tiles.  What kvq_collect_skipped needs to
+    // walk the records such a tile left -- its chunk, what it owns, the newlines of the chunk in front of it, or where the
+    // first record it left begins -- goes to skip_list: the redo is enqueued behind this kernel without the host looking
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     uint32_t total = 0;                        // newlines of the chunk
@@ -1132,7 +1134,18 @@ kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, co
         if (kvq_tile_report_bad(rep, g == tile_first[c], seen, total)) bad = true;
         if ((rep & TR_FLAG_SKIPPED) && skip_list) {
             const unsigned int k = atomicAdd(spec_fail, 0x100u) >> 8;
-            if (k < KVQ_SKIP_CAP) skip_list[k] = make_uint4(g, seen, tile_report[tile_first[nchunks] + g], 0u); else bad = true;
+            if (k < KVQ_SKIP_CAP) {
+                // tile geometry as kvq_seeded_launch made it
+                const uint32_t a = chunk_off[c], e = chunk_off[c + 1], tn = g - tile_first[c];
+                const uint32_t g0 = (a & ~15u) + tn * tile_bytes;
+                KvqSkippedTile T;
+                T.a = a; T.b = e; T.own_begin = tn == 0 ? a : g0; T.own_end = (uint64_t)g0 + tile_bytes < e ? g0 + tile_bytes : e;
+                T.seen = seen; T.first = tn == 0 ? 1u : 0u;
+                // (a tile that has scanned the records in front of z - 1: the walk begins there, at a record's first byte)
+                const uint32_t z = tile_report[tile_first[nchunks] + g];
+                if (z) { T.a = T.own_begin = z - 1u; T.seen = 0; T.first = 1u; }
+                skip_list[k] = T;
+            } else bad = true;
         }
         seen += rep & 0xFFFFu;
     }
@@ -1145,9 +1158,10 @@ kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, co
 
 // one thread per chunk: per-tile table {chunk begin, chunk end, tile number inside the chunk, chunk}
 extern "C" __global__ void __launch_bounds__(256)
-kvq_expand_tiles(uint32_t nchunks, const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ tile_first, uint4 *__restrict__ tile_tab)
+kvq_expand_tiles(uint32_t nchunks, const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ tile_first, uint4 *__restrict__ tile_tab, unsigned int *__restrict__ redo_count)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && redo_count) *redo_count = 0;             // (records that skipped tiles leave are counted afresh for this launch)
     if (c >= nchunks) return;
     const uint32_t a = chunk_off[c], b = chunk_off[c + 1], g0 = tile_first[c];
     for (uint32_t g = g0; g < tile_first[c + 1]; g++) tile_tab[g] = make_uint4(a, b, g - g0, c);

@@ -72,7 +72,17 @@ struct Batch {
 };
 
 struct kvq_comm;
+#define KVQ_REDO_CAP 16384u            // records that the skipped tiles of one launch may leave (beyond: the batch is redone as a whole)
+struct KvqRedo {                      // where the pieces lie inside kvq_scan::d_redo
+    unsigned int *count; uint32_t *nl4, *rec_start, *read_off; int32_t *read_len;
+    static size_t bytes() { return 256 + (size_t)KVQ_REDO_CAP * (16 + 4 + 4 + 4); }
+    explicit KvqRedo(void *p) { char *c = (char *)p; count = (unsigned int *)c; nl4 = (uint32_t *)(c + 256); rec_start = nl4 + 4 * (size_t)KVQ_REDO_CAP; read_off = rec_start + KVQ_REDO_CAP; read_len = (int32_t *)(read_off + KVQ_REDO_CAP); }
+};
 int kvq_live_scans();                 // scan objects alive in this process
+// the persistent scan kernels of a process run one behind the other (two at once only get in each other's way): a launch waits for
+// the event the last one published, on its own stream, right in front of its scan kernel -- its table upload and kvq_expand_tiles do not wait
+int kvq_chain_wait(struct kvq_scan *s);
+int kvq_chain_publish(struct kvq_scan *s);
 uint32_t kvq_device_cu_count();       // compute units of the current device
 int kvq_comm_reduce_counters(kvq_comm *c, const unsigned long long *d_in, unsigned long long *d_out, int64_t ctr_len, unsigned long long *d_scratch, hipStream_t stream);
 int kvq_comm_max_status(kvq_comm *c, unsigned long long mine, unsigned long long *d_scratch, hipStream_t stream, unsigned long long *out);
@@ -86,6 +96,8 @@ struct kvq_scan {
     unsigned long long *d_ctr = nullptr; bool own_ctr = false;
     std::vector<int64_t> h_ctr;
     // per-batch scratch
+    bool seen_skips = false;           // a tile of this scan object has left records to the redo before (kept across resets: sizes the redo's launches)
+    DevBuf d_redo;                     // the redo of skipped tiles (KvqRedo: count, newline quadruples, record starts, trimmed reads)
     DevBuf d_skipped, d_chunk_off, d_seg_base, d_seg_cnt, d_chunk_nrec, d_rec_base, d_nl4, d_rec_start, d_read_off, d_read_len;
     // hit arena
     DevBuf d_covdiff;                  // coverage marks (KvqParams::covdiff)

@@ -42,14 +42,14 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     const uint32_t per_cu = v1 ? 2u : 4u;
     const uint32_t grid_full = cus * per_cu, grid_shared = grid_full - cus / 8u;
     const uint32_t grid_cap = grid_env ? grid_env : (!v1 && kvq_live_scans() > 1) ? grid_shared : grid_full;
-    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 24 + 24576 + KVQ_SKIP_CAP * 16 > s->pool.cap) {       // run_batch made the room
+    if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 24 + 24576 + KVQ_SKIP_CAP * sizeof(KvqSkippedTile) > s->pool.cap) {       // run_batch made the room
         kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;
     }
     // first tile of every chunk, then the parameter block: one copy
     const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
     const size_t ctr_b = 256 + 4 * BP_SHARDS * BP_SHARD_STRIDE;                  // the tile counters (kvq_scan_seeded: one; kvq_scan_bp: BP_SHARDS)
     const size_t first_at = s->pool.take(first_b + sizeof(BpArgs) + ctr_b);      // ... and the tile counters behind it
-    const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 8), skip_at = s->pool.take(KVQ_SKIP_CAP * 16);      // (report: a word per tile, then a word per tile for the records a skipping tile kept)
+    const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 8), skip_at = s->pool.take(KVQ_SKIP_CAP * sizeof(KvqSkippedTile));      // (report: a word per tile, then a word per tile for the records a skipping tile kept)
     s->cur_skip_at = skip_at; s->cur_first_at = first_at; s->cur_ntiles = (uint32_t)nt;
     uint32_t *first = reinterpret_cast<uint32_t *>(s->pool.h + first_at);
     uint64_t acc = 0;
@@ -87,10 +87,12 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     // chunk offsets (run_batch put them right in front), first tiles, arguments, tile counters: one transfer
     KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, ctr_at + 4 * BP_SHARDS * BP_SHARD_STRIDE - s->cur_co_at,
                            hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk));
+    hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk),
+                       s->d_redo.p ? KvqRedo(s->d_redo.p).count : (unsigned int *)nullptr);
 
     // the scan kernel alone between the pair of events its time is read from (bench.py's roofline figure; rocprofv3 --kernel-trace
     // gives the same duration): the table upload, kvq_expand_tiles and kvq_validate_tiles stand outside
+    { const int rcw = kvq_chain_wait(s); if (rcw) return rcw; }                 // behind the last scan kernel of this process (any scan object's)
     const bool timed = !s->ev_main.empty();
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream));
     typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t, unsigned int *);
@@ -143,9 +145,10 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         }
     }
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
+    { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }              // (kvq_validate_tiles and what follows run beside the next scan)
     if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
-                       d_first, d_report, s->cur_fail, v1 ? (uint4 *)nullptr : reinterpret_cast<uint4 *>(s->pool.d + skip_at));
+                       d_first, d_report, s->cur_fail, v1 ? (KvqSkippedTile *)nullptr : reinterpret_cast<KvqSkippedTile *>(s->pool.d + skip_at), d_chunk_off, TILE);
     KVQ_HIP(hipGetLastError());
     if (getenv("KVQ_DBG_REPORT")) {
         // diagnostic: replay kvq_validate_tiles on the host and name the tiles it rejects

@@ -297,6 +297,7 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     s->d_fail = (unsigned int *)((char *)s->d_small.p + SMALL_FAIL);
     s->d_stage_ctr = (unsigned long long *)((char *)s->d_small.p + SMALL_STAGE);
     if (ensure_arena(s, 1u << 20, 64ull << 20) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
+    if (s->d_redo.ensure(KvqRedo::bytes()) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     s->pin_cap = (size_t)t->ctr_len * 8 + (4u << 20);
     if (hipHostMalloc((void **)&s->pin_small, 64 + 4 * (size_t)KVQ_MAX_BATCHES + 512, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&s->pin, s->pin_cap, hipHostMallocDefault) != hipSuccess) {
@@ -319,16 +320,19 @@ static std::mutex g_chain_lock;
 static hipEvent_t g_chain_done = nullptr;         // recorded behind the main kernel enqueued last
 static const kvq_scan *g_chain_owner = nullptr;   // (the event is its: forgotten when that scan goes away)
 
-static int chain_wait(kvq_scan *s)
+int kvq_chain_wait(kvq_scan *s)
 {
     std::lock_guard<std::mutex> l(g_chain_lock);
     if (g_chain_done && g_chain_owner != s) KVQ_HIP(hipStreamWaitEvent(s->stream, g_chain_done, 0));
     return KVQ_OK;
 }
-static void chain_publish(kvq_scan *s, hipEvent_t done)
+int kvq_chain_publish(kvq_scan *s)
 {
+    if (!s->ev_chain) KVQ_HIP(hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming));
+    KVQ_HIP(hipEventRecord(s->ev_chain, s->stream));
     std::lock_guard<std::mutex> l(g_chain_lock);
-    g_chain_done = done; g_chain_owner = s;
+    g_chain_done = s->ev_chain; g_chain_owner = s;
+    return KVQ_OK;
 }
 static void chain_forget(const kvq_scan *s)
 {
@@ -358,7 +362,7 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     if (s->pin_small) (void)hipHostFree(s->pin_small);
     if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
     if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
-    DevBuf *bufs[] = { &s->d_ctr_all, &s->d_gather_cnt, &s->d_gather_res, &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_order, &s->d_finish, &s->d_covdiff, &s->d_skipped, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
+    DevBuf *bufs[] = { &s->d_redo, &s->d_ctr_all, &s->d_gather_cnt, &s->d_gather_res, &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_order, &s->d_finish, &s->d_covdiff, &s->d_skipped, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
                        &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
     for (DevBuf *b : bufs) b->release();
     s->pool.release();
@@ -463,15 +467,11 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     bool hist_done = false;
     if (use_seeded) {
         if ((rc = new_event_pair(s, s->ev_main))) return rc;
-        if ((rc = chain_wait(s))) return rc;
         KvqParams PS = P;                          // counters and error of this batch are staged until it is validated (the pair of events is recorded right around the scan kernel: kvq_seeded_launch)
         PS.ctr = s->d_stage_ctr; PS.err = s->d_err_stage;
         s->cur_fail = s->d_fail + batch_no;
         if ((rc = kvq_seeded_launch(s, PS, d_data, nbytes, d_co, nchunks, fpos_base, maxchunk))) return rc;
         s->batches[batch_no].skip_at = s->cur_skip_at; s->batches[batch_no].tile_bytes = s->tile_bytes;
-        if (!s->ev_chain) KVQ_HIP(hipEventCreateWithFlags(&s->ev_chain, hipEventDisableTiming));
-        KVQ_HIP(hipEventRecord(s->ev_chain, s->stream));
-        chain_publish(s, s->ev_chain);
         s->main_launches++; s->path_bits |= 1;
         hist_done = true;
     }
@@ -513,16 +513,41 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
             }
             const uint32_t per_block = 4 * 16;       // KVQ_TRIM_RPW records per wave
             hipLaunchKernelGGL(kvq_trim_records, dim3((uint32_t)((R + per_block - 1) / per_block)), dim3(256), 0, s->stream, P, d_data,
-                               fpos_base, (uint32_t)R, s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(),
+                               fpos_base, (uint32_t)R, KvqDevCount{ nullptr, 0, 0, nullptr }, s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(),
                                s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), hist_done ? 0 : 1, 16u);
             if (n_exh > 0) {
                 const bool main_here = !use_seeded;
                 if (main_here) { if ((rc = new_event_pair(s, s->ev_main))) return rc; KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream)); }
-                hipLaunchKernelGGL(kvq_match_all, dim3((uint32_t)((R + 3) / 4)), dim3(256), 0, s->stream, P, d_data, fpos_base, (uint32_t)R,
+                hipLaunchKernelGGL(kvq_match_all, dim3((uint32_t)((R + 3) / 4)), dim3(256), 0, s->stream, P, d_data, fpos_base, (uint32_t)R, KvqDevCount{ nullptr, 0, 0, nullptr },
                                    s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), d_exh, n_exh);
                 if (main_here) { KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream)); s->main_launches++; }
             }
         }
+    }
+    // The records of tiles that the fused scan skipped (a record longer than the tile's look-ahead, more newlines than a
+    // tile's tables hold) go through the exhaustive kernels for the seeded sequences -- found again from the exact newline
+    // counts (kvq_collect_skipped walks them from what kvq_validate_tiles wrote for each such tile), trimmed, matched --
+    // right here, behind every seed-filter launch, WITHOUT the host looking: the kernels are launched with fixed grids, read
+    // the number of tiles and of records from device memory and return at once when there are none (the usual case: three
+    // empty launches).  A batch that failed validation is left alone (it is redone as a whole), and so is one whose
+    // skipped tiles hold more records than KVQ_REDO_CAP (kvq_dev_count raises its fail bit).  Their hits lie in the
+    // batch's own range of the arena, closed below.
+    if (use_seeded && s->t->index && s->t->index->variant != 1) {
+        const KvqRedo Rd(s->d_redo.p);
+        unsigned int *const failw = s->d_fail + batch_no;
+        const KvqSkippedTile *tiles = reinterpret_cast<const KvqSkippedTile *>(s->pool.d + s->cur_skip_at);
+        const KvqDevCount ntile{ failw, 8, KVQ_SKIP_CAP, failw }, nrec{ Rd.count, 0, KVQ_REDO_CAP, failw };
+        hipLaunchKernelGGL(kvq_collect_skipped, dim3(16), dim3(256), 0, s->stream, d_data, tiles, 0u, ntile, Rd.nl4, Rd.rec_start, Rd.count, KVQ_REDO_CAP);
+        // (few records, some of them very long: a wave per record for the trim; the matcher shares a record's sequences and
+        // alignments out over many waves)
+        hipLaunchKernelGGL(kvq_trim_records, dim3(32), dim3(256), 0, s->stream, P, d_data, fpos_base, 0u, nrec, Rd.nl4, Rd.rec_start, Rd.read_off, Rd.read_len, 1, 1u);
+        // (the matcher's grid: small as long as this scan object has never had a skipped tile -- an empty launch of sixteen
+        // thousand workgroups costs 50 us, one of 256 next to nothing -- wide once it has: a handful of records of thousands
+        // of bases against every sequence is only quick when it is spread out)
+        const dim3 mgrid = s->seen_skips ? dim3(8, (uint32_t)std::min<size_t>(s->t->seeded.size(), 128), 16) : dim3(4, (uint32_t)std::min<size_t>(s->t->seeded.size(), 16), 4);
+        if (!s->t->seeded.empty())
+            hipLaunchKernelGGL(kvq_match_all, mgrid, dim3(256), 0, s->stream, P, d_data, fpos_base, 0u, nrec,
+                               Rd.read_off, Rd.read_len, s->t->d_seeded.as<int32_t>(), (int32_t)s->t->seeded.size());
     }
     // hits of this batch = arena[range[batch_no], range[batch_no + 1]) (kvq_commit_batch closes the range)
     if (use_seeded)
@@ -535,89 +560,6 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     KVQ_HIP(hipEventRecord(s->ev_all.back().second, s->stream));
     KVQ_HIP(hipGetLastError());
     if (g_timing) fprintf(stderr, "run_batch host %.3f ms\n", now_ms() - tb0);
-    return KVQ_OK;
-}
-
-// The records of the tiles that batch b's fused scan skipped (a record longer than the tile's look-ahead,
-// more newlines than a tile's tables hold): found again from the exact newline counts
-// (kvq_collect_skipped) and put through the exhaustive kernels for the seeded sequences -- a handful of
-// records instead of the whole batch.  Its hits form a batch of their own (appended to s->batches).
-static int redo_skipped(kvq_scan *s, size_t b, uint32_t nskip, const uint8_t *d_data)
-{
-    const kvq_table *t = s->t;
-    if (nskip > KVQ_SKIP_CAP) nskip = KVQ_SKIP_CAP;
-    const Batch src = s->batches[b];
-    std::vector<uint4> list(nskip);
-    KVQ_HIP(hipStreamSynchronize(s->stream));
-    KVQ_HIP(hipMemcpy(list.data(), s->pool.d + src.skip_at, (size_t)nskip * 16, hipMemcpyDeviceToHost));
-    // tile geometry as kvq_seeded_launch made it
-    const uint32_t TILE = src.tile_bytes;
-    const int64_t nchunks = (int64_t)src.chunk_off.size() - 1;
-    std::vector<uint32_t> first((size_t)nchunks + 1);
-    uint64_t acc = 0;
-    for (int64_t c = 0; c < nchunks; c++) {
-        const uint32_t a = (uint32_t)src.chunk_off[c], e = (uint32_t)src.chunk_off[c + 1];
-        first[c] = (uint32_t)acc;
-        acc += e > a ? (uint32_t)(((uint64_t)e - (a & ~15u) + TILE - 1) / TILE) : 0u;
-    }
-    first[nchunks] = (uint32_t)acc;
-    std::vector<KvqSkippedTile> tiles(nskip);
-    for (uint32_t i = 0; i < nskip; i++) {
-        const uint32_t g = list[i].x;
-        const size_t c = (size_t)(std::upper_bound(first.begin(), first.end(), g) - first.begin()) - 1;
-        const uint32_t a = (uint32_t)src.chunk_off[c], e = (uint32_t)src.chunk_off[c + 1], tn = g - first[c];
-        const uint32_t g0 = (a & ~15u) + tn * TILE;
-        KvqSkippedTile T;
-        T.a = a; T.b = e; T.own_begin = tn == 0 ? a : g0; T.own_end = (uint64_t)g0 + TILE < e ? g0 + TILE : e;
-        T.seen = list[i].y; T.first = tn == 0 ? 1u : 0u;
-        // (the tile has scanned the records in front of list[i].z - 1: the walk begins there, at a record's first byte)
-        if (list[i].z) { T.a = T.own_begin = list[i].z - 1u; T.seen = 0; T.first = 1u; }
-        tiles[i] = T;
-    }
-    // a record has four newlines: a tile of TILE bytes owns at most TILE / 4 of them
-    const uint32_t rec_cap = (uint32_t)std::min<uint64_t>((uint64_t)nskip * (TILE / 4u + 1u), 1u << 26);
-    int rc;
-    if ((rc = s->d_skipped.ensure((size_t)nskip * sizeof(KvqSkippedTile) + 64))) return rc;
-    if ((rc = s->d_nl4.ensure((size_t)rec_cap * 16))) return rc;
-    if ((rc = s->d_rec_start.ensure((size_t)rec_cap * 4))) return rc;
-    unsigned int *d_count = reinterpret_cast<unsigned int *>((char *)s->d_skipped.p + (((size_t)nskip * sizeof(KvqSkippedTile) + 15) & ~(size_t)15));
-    KVQ_HIP(hipMemcpyAsync(s->d_skipped.p, tiles.data(), (size_t)nskip * sizeof(KvqSkippedTile), hipMemcpyHostToDevice, s->stream));
-    KVQ_HIP(hipMemsetAsync(d_count, 0, 4, s->stream));
-    hipLaunchKernelGGL(kvq_collect_skipped, dim3((nskip + 3) / 4), dim3(256), 0, s->stream, d_data, s->d_skipped.as<KvqSkippedTile>(), nskip,
-                       s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(), d_count, rec_cap);
-    unsigned int R = 0;
-    KVQ_HIP(hipMemcpyAsync(&R, d_count, 4, hipMemcpyDeviceToHost, s->stream));
-    KVQ_HIP(hipStreamSynchronize(s->stream));
-    if (R > rec_cap) { kvq_set_error(KVQ_ERR_RUNTIME, "skipped tiles hold more records than a tile can"); return KVQ_ERR_RUNTIME; }
-    if (g_timing) {
-        fprintf(stderr, "redo_skipped: %u tiles, %u records\n", nskip, R);
-        for (uint32_t i = 0; i < nskip && i < 16; i++) fprintf(stderr, "  tile %u seen %u: chunk [%u, %u) owns [%u, %u) first %u\n", list[i].x, list[i].y, tiles[i].a, tiles[i].b, tiles[i].own_begin, tiles[i].own_end, tiles[i].first);
-    }
-    // the records' hits: a batch of their own
-    Batch again = src; again.is_redo = true; again.redone = false; again.skips_done = true;
-    s->batches.push_back(again);
-    const size_t batch_no = s->batches.size() - 1;
-    if (batch_no >= KVQ_MAX_BATCHES) { kvq_set_error(KVQ_ERR_RUNTIME, "too many batches in one scan"); return KVQ_ERR_RUNTIME; }
-    KvqParams P = make_params(s);
-    if (R > 0) {
-        if ((rc = s->d_read_off.ensure((size_t)R * 4))) return rc;
-        if ((rc = s->d_read_len.ensure((size_t)R * 4))) return rc;
-        // few records, some of them very long: a wave per record for the trim; for the matcher a record's sequences
-        // -- and, when the records are really few, its alignments too -- are shared out over many waves
-        const bool few = R <= 256;
-        const uint32_t trim_rpw = few ? 1u : 16u;
-        hipLaunchKernelGGL(kvq_trim_records, dim3((R + 4 * trim_rpw - 1) / (4 * trim_rpw)), dim3(256), 0, s->stream, P, d_data, src.fpos_base, (uint32_t)R,
-                           s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(), s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), 1, trim_rpw);
-        if (!t->seeded.empty())
-            hipLaunchKernelGGL(kvq_match_all, dim3((R + 3) / 4, (uint32_t)std::min<size_t>(t->seeded.size(), few ? 1024 : 64), few ? 8u : 1u), dim3(256), 0, s->stream,
-                               P, d_data, src.fpos_base, (uint32_t)R,
-                               s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), t->d_seeded.as<int32_t>(), (int32_t)t->seeded.size());
-    }
-    KVQ_HIP(hipMemcpyAsync(s->d_range + batch_no + 1, s->d_arena_n, 4, hipMemcpyDeviceToDevice, s->stream));
-    hipLaunchKernelGGL(kvq_fold_batch, dim3(512), dim3(256), 0, s->stream, P, d_data, src.fpos_base,
-                       (const unsigned int *)(s->d_range + batch_no), (const unsigned int *)(s->d_range + batch_no + 1));
-    KVQ_HIP(hipGetLastError());
-    s->path_bits |= 8 | 2;
     return KVQ_OK;
 }
 
@@ -660,14 +602,7 @@ extern "C" int32_t kvq_scan_host_drain(kvq_scan *s)
     if (!(s->path_bits & 1)) return KVQ_OK;
     const unsigned int fail = *reinterpret_cast<const unsigned int *>(s->pin_small + 40);     // copied behind the batch
     if (!fail) return KVQ_OK;
-    if (!(fail & 1u)) {
-        // only some tiles were skipped: their records again, while the text is still in the staging buffer
-        s->batches[b].skips_done = true;
-        int rc = redo_skipped(s, b, fail >> 8, s->d_stage.as<uint8_t>());
-        if (rc) return rc;
-        KVQ_HIP(hipStreamSynchronize(s->stream));
-        return KVQ_OK;
-    }
+    if (!(fail & 1u)) { s->path_bits |= 8 | 2; s->seen_skips = true; return KVQ_OK; }      // only some tiles were skipped: their records have been through the exhaustive kernels behind the scan (run_batch)
     s->batches[b].redone = true;
     s->tile_bytes = kvq_choose_tile(1u << 20, 0); s->rec_bytes = 0;  // (a record may have outgrown the look-ahead: back to the full one)
     Batch again = s->batches[b]; again.is_redo = true;
@@ -784,14 +719,7 @@ static int finish_once(kvq_scan *s)
             bool any = false;
             for (size_t b = 0; b < nb0; b++) {
                 if (!fail[b] || s->batches[b].redone || s->batches[b].is_redo || !s->batches[b].d_data) continue;
-                if (!(fail[b] & 1u)) {
-                    // only some tiles were skipped: their records again
-                    if (s->batches[b].skips_done) continue;
-                    s->batches[b].skips_done = true;
-                    if ((rc = redo_skipped(s, b, fail[b] >> 8, s->batches[b].d_data))) return rc;
-                    any = true;
-                    continue;
-                }
+                if (!(fail[b] & 1u)) { s->path_bits |= 8 | 2; s->seen_skips = true; continue; }      // only some tiles were skipped: their records went through the exhaustive kernels behind the scan (run_batch)
                 s->batches[b].redone = true;
                 s->tile_bytes = kvq_choose_tile(1u << 20, 0); s->rec_bytes = 0;   // (a record may have outgrown the look-ahead: back to the full one)
                 Batch again = s->batches[b]; again.is_redo = true;
