@@ -77,6 +77,7 @@ def main():
     ap.add_argument('--batch-bytes', type=int, default=(1 << 32) - (1 << 20), help='largest batch handed to kvq_scan_device')
     ap.add_argument('--preheat', type=int, default=30, help='untimed scans before the warmup steps (the GPU clocks take ~10 steps = 20 ms to settle in a fresh process)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-end-to-end', action='store_true', help='skip the file -> engine.findseqs -> Python result measurement behind the timed region')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of the CPU baseline sample')
     args = ap.parse_args()
 
@@ -286,6 +287,7 @@ def main():
                    'parallelism': 'read-shard x%d, counter arrays summed by %s' % (world, reduce_by) if world > 1 else 'single GPU',
                    'kernel_path': 'exhaustive' if args.exhaustive or not any(table.seeded) else
                                   'seed-filter k=%d (%d of %d sequences)' % (table.seed_k, sum(table.seeded), table.nseq),
+                   'join_checked': join_checked,
                    'hits_per_step': total_hits, 'records_per_step': total_records,
                    'preheat_steps': max(0, args.preheat), 'steps_in_flight': depth},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -321,6 +323,8 @@ def main():
                 out['roofline']['traffic_note'] = 'profiles/%s was measured on other kernel sources (%s): not quoted' % (
                     os.path.basename(path), str(pmc.get('source_sha256'))[:12])
             break
+    if world == 1 and not args.no_end_to_end and not args.exhaustive:
+        out['end_to_end'] = end_to_end(d_data, n, rb, seqs, cfg)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(g, seqs, cfg, L, rb, args.cpu_seconds)
     print(json.dumps(out))
@@ -341,6 +345,32 @@ def source_sha256():
         with open(path, 'rb') as f:
             h.update(f.read())
     return h.hexdigest()
+
+
+def end_to_end(d_data, n, rb, seqs, cfg, nthreads=8):
+    """the same records as a page-cache-warm FastQ file through engine.findseqs to the Python result (hits, hit
+    bytes, stats): host read + PCIe + kernels + result -- SURVEY 8d's "end-to-end" next to the HBM-resident `value`
+    (never `value` itself).  Outside the timed region; the best of three calls."""
+    from kvarq_amd import engine
+    path = '/tmp/kvarq_bench_e2e.fastq'
+    try:
+        d_data.download().tofile(path)
+        engine.config(nthreads=nthreads, **cfg)
+        best, hits = None, 0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = engine.findseqs(path, seqs)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+            hits = len(r['hits'])
+            assert r['stats']['records_parsed'] == n, 'end to end: records lost'
+        return {'reads_per_s': n / best, 'GB_per_s': n * rb / best / 1e9, 'file_bytes': n * rb, 'nthreads': nthreads, 'hits': hits,
+                'seconds': best, 'what': 'engine.findseqs on a page-cache-warm plain FastQ file of the same records: pread into pinned buffers, PCIe, kernels, ordered hits and stats as Python objects'}
+    except Exception as e:              # noqa: BLE001 -- a full /tmp must not cost the bench line
+        return {'error': str(e)[:200]}
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
 
 
 def cpu_baseline(g, seqs, cfg, L, rb, seconds):

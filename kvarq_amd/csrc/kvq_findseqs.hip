@@ -619,6 +619,8 @@ static int stream_batches(Sink &sink, const char *const *files, int nfiles, uint
     int rc = src.open(files, nfiles);
     if (rc) return rc;
     sink.begin(src.total());
+    double t_read = 0, t_cut = 0, t_sink = 0, t_carry = 0; int64_t nbatch = 0;       // (KVQ_TIMING=1: where the host's time goes)
+    struct Report { double &a, &b, &c, &d; int64_t &n; ~Report() { if (g_timing) fprintf(stderr, "stream_batches: %lld batches; read %.1f  cut %.1f  sink (wait for the last batch + enqueue) %.1f  carry %.1f ms\n", (long long)n, a, b, c, d); } } report{ t_read, t_cut, t_sink, t_carry, nbatch };
 
     while (src.has_next_file() && !g_stop.load()) {
         if ((rc = src.open_next())) return rc;
@@ -629,12 +631,14 @@ static int stream_batches(Sink &sink, const char *const *files, int nfiles, uint
         bool eof = false;
         while (!g_stop.load()) {
             // top up
+            const double tr0 = now_ms();
             while (!eof && have < pin_cap) {
                 const int64_t n = src.read(pin + have, pin_cap - have, &eof);
                 if (n < 0) return kvq_error_code();
                 have += n;
                 if (n == 0 && !eof) break;
             }
+            const double tr1 = now_ms(); t_read += tr1 - tr0;
             // cut chunks the way fastq_read does (workhorse.c:737-956)
             std::vector<int64_t> off;
             bool file_finished = false;
@@ -657,13 +661,16 @@ static int stream_batches(Sink &sink, const char *const *files, int nfiles, uint
             }
             const int64_t batch_begin = off.empty() ? cs : off[0];
             const int64_t batch_end = cs;
+            const double tr2 = now_ms(); t_cut += tr2 - tr1;
             if (!off.empty()) {
                 off.push_back(batch_end);
                 for (auto &o : off) o -= batch_begin;
                 rc = sink.batch(pin + batch_begin, batch_end - batch_begin, off.data(), (int64_t)off.size() - 1,
                                 pin_fpos + batch_begin, src.fpos(), src.total());
                 if (rc) return rc;
+                nbatch++;
             }
+            const double tr3 = now_ms(); t_sink += tr3 - tr2;
             if (file_finished) {
                 if (pin2 && !off.empty()) std::swap(pin, pin2);       // the next file starts in the other buffer
                 break;
@@ -674,6 +681,7 @@ static int stream_batches(Sink &sink, const char *const *files, int nfiles, uint
             if (pin2 && !off.empty()) { memcpy(pin2, pin + cs, (size_t)carry); std::swap(pin, pin2); }
             else memmove(pin, pin + cs, (size_t)carry);
             pin_fpos += cs; fill -= cs; have = carry; cs = 0;
+            t_carry += now_ms() - tr3;
         }
     }
     *parsed = src.fpos(); *total = src.total();
@@ -686,11 +694,9 @@ struct ScanSink {
     void begin(int64_t total) { live_reset(s->t->nseq, total); ctr_live.resize((size_t)s->t->ctr_len); }
     int batch(const uint8_t *data, int64_t nbytes, const int64_t *off, int64_t nchunks, int64_t fpos, int64_t parsed, int64_t total)
     {
-        // the batch handed over last has been read from its host buffer and scanned by now or soon:
-        // wait for it, publish its counters (engine.stats() may be polling), then enqueue this one and
-        // return, so that the reader fills the other host buffer while this one is copied and scanned
-        int rc = kvq_scan_host_drain(s);
-        if (rc) return rc;
+        // publish the counters so far (engine.stats() may be polling), hand this batch over (its text sets out at once, the
+        // kernels of the batch before it are enqueued: kvq_scan_host_async) and return, so that the reader fills the other
+        // host buffer while this one crosses PCIe
         if (have_live) {
             if (hipMemcpy(ctr_live.data(), s->d_ctr, (size_t)s->t->ctr_len * 8, hipMemcpyDeviceToHost) != hipSuccess) {
                 kvq_set_error(KVQ_ERR_DEVICE, "device failure during scan"); return KVQ_ERR_DEVICE;

@@ -113,12 +113,18 @@ struct kvq_scan {
     size_t cur_skip_at = 0, cur_first_at = 0; uint32_t cur_ntiles = 0;   // the batch's list of skipped tiles, its first-tile table
     TablePool pool;
     // staging for host batches
-    DevBuf d_stage;
+    // Host batches: two staging buffers.  A batch's text crosses PCIe on copy_stream as soon as it is handed over; its
+    // kernels are enqueued one call later, when the batch in front of it has been settled -- the copy engine never waits
+    // for kernels, the kernels never wait for the host
+    DevBuf d_stage, d_stage_b;
+    int run_slot = 1;                    // the buffer of the batch whose kernels are in flight (the next text goes to the other one)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy[2] = { nullptr, nullptr };
+    bool copied_pending = false; int copied_slot = 0; Batch copied;   // the batch whose text is on its way (or there), kernels not yet enqueued
     // replay list (device batches) + bookkeeping
     std::vector<Batch> batches;
     bool host_batches = false;
     int64_t host_pending = -1;           // index of the host batch in flight (kvq_scan_host_async), -1: none
-    hipEvent_t ev_copied = nullptr;      // its text has left the host buffer
     hipEvent_t ev_chain = nullptr;       // this scan's last seed-filter launch is through, kvq_validate_tiles included (what the next scan of the process waits for)
     int64_t records = 0;
     int64_t parsed = 0, total = 0;

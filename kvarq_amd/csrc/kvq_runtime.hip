@@ -360,10 +360,11 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     if (s->own_ctr && s->d_ctr) (void)hipFree(s->d_ctr);
     if (s->pin) (void)hipHostFree(s->pin);
     if (s->pin_small) (void)hipHostFree(s->pin_small);
-    if (s->ev_copied) (void)hipEventDestroy(s->ev_copied);
+    for (int i = 0; i < 2; i++) if (s->ev_copy[i]) (void)hipEventDestroy(s->ev_copy[i]);
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
     DevBuf *bufs[] = { &s->d_redo, &s->d_ctr_all, &s->d_gather_cnt, &s->d_gather_res, &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_order, &s->d_finish, &s->d_covdiff, &s->d_skipped, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
-                       &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage };
+                       &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage, &s->d_stage_b };
     for (DevBuf *b : bufs) b->release();
     s->pool.release();
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -379,7 +380,8 @@ extern "C" int32_t kvq_scan_reset(kvq_scan *s)
     const double tr0 = now_ms();
     KVQ_HIP(hipStreamSynchronize(s->stream));
     drop_events(s);
-    s->batches.clear(); s->host_batches = false; s->host_pending = -1; s->records = 0; s->parsed = 0; s->total = 0;
+    if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+    s->batches.clear(); s->host_batches = false; s->host_pending = -1; s->copied_pending = false; s->records = 0; s->parsed = 0; s->total = 0;
     s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->reduced = false; s->gathered = false; s->path_bits = 0; s->n_hits = 0;
     s->pool.used = 0;
     const int rr = reset_device_state(s);
@@ -589,11 +591,12 @@ extern "C" int32_t kvq_scan_device(kvq_scan *s, const void *d_data, int64_t nbyt
     return run_batch(s, (const uint8_t *)d_data, nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1, false);
 }
 
-// Host batches go through one device staging buffer, one batch in flight: while the GPU copies and
-// scans batch k the caller reads batch k+1 into another host buffer.  kvq_scan_host_drain waits for
-// the batch in flight and settles it: when its seed-filter pass failed validation it is scanned
-// again, exhaustively, while its text is still in the staging buffer.
-extern "C" int32_t kvq_scan_host_drain(kvq_scan *s)
+// Host batches.  kvq_scan_host_async(k) sends batch k's text across PCIe at once (copy stream, the staging buffer that is
+// free) and enqueues the kernels of batch k - 1, whose text has arrived meanwhile, behind the settled batch k - 2: copies
+// follow each other without a gap, kernels run beside them, and the host is back reading the next batch while both go on.
+// Settling a batch = waiting for its kernels and looking at its fail word: when its seed-filter pass failed validation it is
+// scanned again, exhaustively, while its text is still in its staging buffer.
+static int settle_in_flight(kvq_scan *s)
 {
     KVQ_HIP(hipStreamSynchronize(s->stream));
     if (s->host_pending < 0) return KVQ_OK;
@@ -608,35 +611,27 @@ extern "C" int32_t kvq_scan_host_drain(kvq_scan *s)
     Batch again = s->batches[b]; again.is_redo = true;
     s->batches.push_back(again);
     s->path_bits |= 4;
-    int rc = run_batch(s, s->d_stage.as<uint8_t>(), again.nbytes, again.chunk_off.data(), (int64_t)again.chunk_off.size() - 1,
+    int rc = run_batch(s, (s->run_slot ? s->d_stage_b : s->d_stage).as<uint8_t>(), again.nbytes, again.chunk_off.data(), (int64_t)again.chunk_off.size() - 1,
                        again.fpos_base, s->batches.size() - 1, true);
     if (rc) return rc;
     KVQ_HIP(hipStreamSynchronize(s->stream));
     return KVQ_OK;
 }
 
-// enqueue one host batch and return; h_data must stay untouched until kvq_scan_host_copied(s)
-// (or the next kvq_scan_host_async / kvq_scan_host_drain / kvq_scan_finish) has returned
-extern "C" int32_t kvq_scan_host_async(kvq_scan *s, const void *h_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base)
+// the kernels of the batch whose text has been sent (the batch in flight has been settled: the table pool is free)
+static int launch_copied(kvq_scan *s)
 {
-    kvq_clear_error();
-    if (nbytes <= 0 || nchunks <= 0) return KVQ_OK;
-    int rc = kvq_scan_host_drain(s); if (rc) return rc;          // the staging buffer and the table pool are free again
-    if ((rc = check_batch(h_data, nbytes, chunk_off, nchunks, s->batches.size(), false))) return rc;
+    if (!s->copied_pending) return KVQ_OK;
+    s->copied_pending = false;
+    const int slot = s->copied_slot;
+    DevBuf &stage = slot ? s->d_stage_b : s->d_stage;
     s->pool.used = 0;
     *reinterpret_cast<unsigned int *>(s->pin_small + 40) = 0;    // "speculation failed" of the batch about to be enqueued
-    if (s->tile_bytes == 0)                                      // size the seed-filter tiles from the head of the text
-        s->tile_bytes = kvq_tile_for_text((const uint8_t *)h_data, (size_t)std::min<int64_t>(nbytes, 128 << 10), &s->rec_bytes);
-    if ((rc = s->d_stage.ensure((size_t)nbytes + 64))) return rc;
-    if (!s->ev_copied) KVQ_HIP(hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming));
-    KVQ_HIP(hipMemcpyAsync(s->d_stage.p, h_data, (size_t)nbytes, hipMemcpyHostToDevice, s->stream));
-    KVQ_HIP(hipEventRecord(s->ev_copied, s->stream));
-    Batch b; b.d_data = nullptr; b.nbytes = nbytes; b.fpos_base = fpos_base;
-    b.chunk_off.assign(chunk_off, chunk_off + nchunks + 1);
-    s->batches.push_back(b);
-    s->host_batches = true;
-    s->parsed += nbytes; s->total += nbytes;
-    rc = run_batch(s, s->d_stage.as<uint8_t>(), nbytes, chunk_off, nchunks, fpos_base, s->batches.size() - 1, false);
+    KVQ_HIP(hipStreamWaitEvent(s->stream, s->ev_copy[slot], 0));
+    s->batches.push_back(s->copied);
+    const Batch &b = s->batches.back();
+    s->run_slot = slot;
+    int rc = run_batch(s, stage.as<uint8_t>(), b.nbytes, b.chunk_off.data(), (int64_t)b.chunk_off.size() - 1, b.fpos_base, s->batches.size() - 1, false);
     if (rc) return rc;
     if (s->path_bits & 1)
         KVQ_HIP(hipMemcpyAsync(s->pin_small + 40, s->d_fail + (s->batches.size() - 1), 4, hipMemcpyDeviceToHost, s->stream));
@@ -644,10 +639,48 @@ extern "C" int32_t kvq_scan_host_async(kvq_scan *s, const void *h_data, int64_t 
     return KVQ_OK;
 }
 
+// everything handed over so far is scanned and settled
+extern "C" int32_t kvq_scan_host_drain(kvq_scan *s)
+{
+    int rc;
+    if ((rc = settle_in_flight(s))) return rc;
+    if ((rc = launch_copied(s))) return rc;
+    return settle_in_flight(s);
+}
+
+// hand over one host batch and return; h_data must stay untouched until kvq_scan_host_copied(s) (or the next
+// kvq_scan_host_async / kvq_scan_host_drain / kvq_scan_finish) has returned
+extern "C" int32_t kvq_scan_host_async(kvq_scan *s, const void *h_data, int64_t nbytes, const int64_t *chunk_off, int64_t nchunks, int64_t fpos_base)
+{
+    kvq_clear_error();
+    if (nbytes <= 0 || nchunks <= 0) return KVQ_OK;
+    int rc;
+    if ((rc = check_batch(h_data, nbytes, chunk_off, nchunks, s->batches.size() + (s->copied_pending ? 1u : 0u), false))) return rc;
+    if ((rc = settle_in_flight(s))) return rc;                     // the batch whose kernels ran while the caller read this one
+    if ((rc = launch_copied(s))) return rc;                        // the batch handed over last call: its text has arrived meanwhile
+    const int slot = s->run_slot ^ 1;                              // (the buffer of the batch settled just now, or one never used)
+    DevBuf &stage = slot ? s->d_stage_b : s->d_stage;
+    if ((rc = stage.ensure((size_t)nbytes + 64))) return rc;
+    if (!s->copy_stream) KVQ_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) if (!s->ev_copy[i]) KVQ_HIP(hipEventCreateWithFlags(&s->ev_copy[i], hipEventDisableTiming));
+    if (s->tile_bytes == 0)                                      // size the seed-filter tiles from the head of the text
+        s->tile_bytes = kvq_tile_for_text((const uint8_t *)h_data, (size_t)std::min<int64_t>(nbytes, 128 << 10), &s->rec_bytes);
+    KVQ_HIP(hipMemcpyAsync(stage.p, h_data, (size_t)nbytes, hipMemcpyHostToDevice, s->copy_stream));
+    KVQ_HIP(hipEventRecord(s->ev_copy[slot], s->copy_stream));
+    s->copied = Batch(); s->copied.d_data = nullptr; s->copied.nbytes = nbytes; s->copied.fpos_base = fpos_base;
+    s->copied.chunk_off.assign(chunk_off, chunk_off + nchunks + 1);
+    s->copied_pending = true; s->copied_slot = slot;
+    s->host_batches = true;
+    s->parsed += nbytes; s->total += nbytes;
+    // (a caller that alternates two host buffers writes next into the one of the call before: that text has left it)
+    if (s->host_pending >= 0) KVQ_HIP(hipEventSynchronize(s->ev_copy[s->run_slot]));
+    return KVQ_OK;
+}
+
 // wait until the text of the last kvq_scan_host_async batch has left the host buffer
 extern "C" int32_t kvq_scan_host_copied(kvq_scan *s)
 {
-    if (s->ev_copied) KVQ_HIP(hipEventSynchronize(s->ev_copied));
+    if (s->copied_pending && s->ev_copy[s->copied_slot]) KVQ_HIP(hipEventSynchronize(s->ev_copy[s->copied_slot]));
     return KVQ_OK;
 }
 
