@@ -592,7 +592,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         // now and then the read-length histogram goes to the global counters (16-bit bins); waves that are
         // already counting this tile's reads may add to a bin at any time: it is taken and cleared in one step
         if (++tiles_done == ST_HIST_TILES) {
-            unsigned long long *const ctr = bp_args(A_)->P.ctr;
+            unsigned long long *const ctr = (bp_args(A_)->P.ctr + (size_t)(blockIdx.x % KVQ_STAGE_COPIES) * KVQ_STAGE_SLOTS);
             for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) {
                 const uint32_t w = atomicExch(&S.hist[i], 0u);
                 if (w & 0xFFFFu) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i], (unsigned long long)(w & 0xFFFFu));
@@ -888,7 +888,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     if constexpr (STAMPS) rt_loop = __builtin_amdgcn_s_memrealtime();
     atomicMax(&S.longest_p1, my_longest);
     __syncthreads();
-    unsigned long long *const ctr = bp_args(A_)->P.ctr;
+    unsigned long long *const ctr = (bp_args(A_)->P.ctr + (size_t)(blockIdx.x % KVQ_STAGE_COPIES) * KVQ_STAGE_SLOTS);
     if constexpr (STAMPS) {
         if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
         if (lane == 0) atomicAdd(&ctr[KVQ_CTR_RL_ + 908 + wave], wave_p34);

@@ -525,7 +525,7 @@ kvq_scan_pool(const BpArgs *__restrict__ A_)
             }
         }
         if (++tiles_done == ST_HIST_TILES) {
-            unsigned long long *const ctr = bp_args(A_)->P.ctr;
+            unsigned long long *const ctr = (bp_args(A_)->P.ctr + (size_t)(blockIdx.x % KVQ_STAGE_COPIES) * KVQ_STAGE_SLOTS);
             for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) {
                 const uint32_t w = atomicExch(&S.hist[i], 0u);
                 if (w & 0xFFFFu) atomicAdd(&ctr[KVQ_CTR_RL_ + 2 * i], (unsigned long long)(w & 0xFFFFu));
@@ -862,7 +862,7 @@ kvq_scan_pool(const BpArgs *__restrict__ A_)
 
     atomicMax(&S.longest_p1, my_longest);
     __syncthreads();
-    unsigned long long *const ctr = bp_args(A_)->P.ctr;
+    unsigned long long *const ctr = (bp_args(A_)->P.ctr + (size_t)(blockIdx.x % KVQ_STAGE_COPIES) * KVQ_STAGE_SLOTS);
     if constexpr (STAMPS) {
         if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
     }

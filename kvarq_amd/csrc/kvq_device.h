@@ -28,6 +28,10 @@ struct KvqHit {
 #define KVQ_CTR_HITS_ 2
 #define KVQ_CTR_RL_ 4
 #define KVQ_RL_BINS 1024
+// the counters the fused scan kernel adds to are staged per batch (kvq_commit_batch), in KVQ_STAGE_COPIES copies: a workgroup
+// takes the copy of its blockIdx.x % KVQ_STAGE_COPIES
+#define KVQ_STAGE_SLOTS (KVQ_CTR_RL_ + KVQ_RL_BINS)
+#define KVQ_STAGE_COPIES 8
 
 // parameters every scanning kernel needs
 struct KvqParams {

@@ -1,5 +1,5 @@
 // kvarq_amd/csrc/kvq_launch.hip -- enqueueing the fused seed-filter scan of one batch (whichever kernel walks the text:
-// kvq_scan_pool by default, kvq_scan_bp with KVQ_KERNEL=v2, kvq_scan_seeded with KVQ_KERNEL=v1)
+// kvq_scan_bp; kvq_scan_pool, round 3's experiment, with KVQ_KERNEL=pool)
 #include "kvq_host.h"
 
 // ---------------------------------------------------------------------------
@@ -32,22 +32,21 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         if (!s->ev_main.empty()) { KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream)); KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream)); }
         return KVQ_OK;
     }
-    // workgroups per launch: what the CUs hold at once (kvq_scan_bp four per CU, kvq_scan_seeded two)
+    // workgroups per launch: what the CUs hold at once (four per CU)
     static const uint32_t grid_env = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 0);
     // (a process that keeps several scan objects is taken to overlap their work -- the next job's scan with the
     // last one's fold, ordering and copy: one CU in eight then keeps a workgroup slot free, so that those small
     // kernels run beside the persistent workgroups of the scan instead of behind them; tools: bench.py --pipeline)
     static const uint32_t cus = kvq_device_cu_count();
-    const bool v1 = ix->variant == 1;
-    const uint32_t per_cu = v1 ? 2u : 4u;
+    const uint32_t per_cu = 4u;
     const uint32_t grid_full = cus * per_cu, grid_shared = grid_full - cus / 8u;
-    const uint32_t grid_cap = grid_env ? grid_env : (!v1 && kvq_live_scans() > 1) ? grid_shared : grid_full;
+    const uint32_t grid_cap = grid_env ? grid_env : (kvq_live_scans() > 1) ? grid_shared : grid_full;
     if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 24 + 24576 + KVQ_SKIP_CAP * sizeof(KvqSkippedTile) > s->pool.cap) {       // run_batch made the room
         kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;
     }
     // first tile of every chunk, then the parameter block: one copy
     const size_t first_b = (((size_t)nchunks + 1) * 4 + 255) & ~(size_t)255;
-    const size_t ctr_b = 256 + 4 * BP_SHARDS * BP_SHARD_STRIDE;                  // the tile counters (kvq_scan_seeded: one; kvq_scan_bp: BP_SHARDS)
+    const size_t ctr_b = 256 + 4 * BP_SHARDS * BP_SHARD_STRIDE;                  // the tile counters
     const size_t first_at = s->pool.take(first_b + sizeof(BpArgs) + ctr_b);      // ... and the tile counters behind it
     const size_t chunk_at = s->pool.take((size_t)nt * 16), report_at = s->pool.take((size_t)nt * 8), skip_at = s->pool.take(KVQ_SKIP_CAP * sizeof(KvqSkippedTile));      // (report: a word per tile, then a word per tile for the records a skipping tile kept)
     s->cur_skip_at = skip_at; s->cur_first_at = first_at; s->cur_ntiles = (uint32_t)nt;
@@ -69,7 +68,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     const size_t ctr_at = first_at + first_b + ((sizeof(BpArgs) + 127) & ~(size_t)127);
     unsigned int *d_tile_ctr = reinterpret_cast<unsigned int *>(s->pool.d + ctr_at);
     {
-        // the argument block of the scan kernel (kvq_scan_seeded reads its first member, the parameters)
+        // the argument block of the scan kernel
         BpArgs a;
         memset(&a, 0, sizeof(a));
         a.P = P; a.X = ix->dev; a.data = d_data; a.fpos_base = fpos_base;
@@ -81,8 +80,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     {
         unsigned int *hc = reinterpret_cast<unsigned int *>(s->pool.h + ctr_at);
         memset(hc, 0, 4 * BP_SHARDS * BP_SHARD_STRIDE);
-        if (v1) hc[0] = grid_seeded;                                              // kvq_scan_seeded: tiles below this number are the workgroups' first
-        else for (uint32_t sh = 0; sh < BP_SHARDS; sh++) hc[sh * BP_SHARD_STRIDE] = bp_shard_begin(sh, (uint32_t)nt);
+        for (uint32_t sh = 0; sh < BP_SHARDS; sh++) hc[sh * BP_SHARD_STRIDE] = bp_shard_begin(sh, (uint32_t)nt);
     }
     // chunk offsets (run_batch put them right in front), first tiles, arguments, tile counters: one transfer
     KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, ctr_at + 4 * BP_SHARDS * BP_SHARD_STRIDE - s->cur_co_at,
@@ -95,21 +93,9 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     { const int rcw = kvq_chain_wait(s); if (rcw) return rcw; }                 // behind the last scan kernel of this process (any scan object's)
     const bool timed = !s->ev_main.empty();
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream));
-    typedef void (*SeededKernel)(const KvqParams *, SeedTables, const uint8_t *, int64_t, const uint4 *, uint32_t, uint32_t *, uint32_t, uint32_t, unsigned int *);
     typedef void (*BpKernel)(const BpArgs *);
     const int si = ix->stride == 8 ? 2 : ix->stride == 4 ? 1 : 0, st = (dbg & 16u) ? 3 : 0;
-    if (v1) {
-        static const SeededKernel kernels[6] = { kvq_scan_seeded<2, false>, kvq_scan_seeded<4, false>, kvq_scan_seeded<8, false>,
-                                                 kvq_scan_seeded<2, true>, kvq_scan_seeded<4, true>, kvq_scan_seeded<8, true> };
-        static bool attr_set = false;
-        if (!attr_set) {
-            for (SeededKernel kf : kernels)
-                KVQ_HIP(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeededLds)));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kernels[si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_params, ix->dev, d_data, fpos_base,
-                           reinterpret_cast<const uint4 *>(d_tchunk), (uint32_t)nt, d_report, dbg, TILE, d_tile_ctr);
-    } else {
+    {
         // the lane group of a read: four lanes, fixed at compile time, when that is the widest power of two
         // that gives every read of a full tile its own lanes (records of 100 to 250 bases); otherwise the
         // kernel that works the width out per tile
@@ -148,7 +134,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }              // (kvq_validate_tiles and what follows run beside the next scan)
     if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
-                       d_first, d_report, s->cur_fail, v1 ? (KvqSkippedTile *)nullptr : reinterpret_cast<KvqSkippedTile *>(s->pool.d + skip_at), d_chunk_off, TILE);
+                       d_first, d_report, s->cur_fail, reinterpret_cast<KvqSkippedTile *>(s->pool.d + skip_at), d_chunk_off, TILE);
     KVQ_HIP(hipGetLastError());
     if (getenv("KVQ_DBG_REPORT")) {
         // diagnostic: replay kvq_validate_tiles on the host and name the tiles it rejects

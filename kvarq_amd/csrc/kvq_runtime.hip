@@ -189,10 +189,9 @@ extern "C" int64_t kvq_table_seq_offset(const kvq_table *t, int32_t s) { return 
 // d_small layout (bytes): [0] arena_n u32, [8] blob_n u64, [16] err u64, [24] err of the batch in flight u64,
 // [64 ..) range words u32 x (KVQ_MAX_BATCHES+1), then per-batch "speculation failed" flags u32 x KVQ_MAX_BATCHES,
 // then the staging counters of the batch in flight (records, longest, read-length histogram)
-#define KVQ_STAGE_SLOTS (KVQ_CTR_RL_ + KVQ_RL_BINS)
 static const size_t SMALL_RANGE = 64, SMALL_FAIL = SMALL_RANGE + 4 * (KVQ_MAX_BATCHES + 1),
                     SMALL_STAGE = (SMALL_FAIL + 4 * KVQ_MAX_BATCHES + 255) & ~(size_t)255,
-                    SMALL_BYTES = SMALL_STAGE + 8 * KVQ_STAGE_SLOTS;
+                    SMALL_BYTES = SMALL_STAGE + 8 * KVQ_STAGE_SLOTS * KVQ_STAGE_COPIES;
 
 // after the kernels of one batch: merge the seed-filter kernel's staged counters and error
 // into the scan's, or -- when its speculated record split failed validation -- forget
@@ -202,10 +201,16 @@ kvq_commit_batch(unsigned long long *stage, unsigned long long *ctr, unsigned lo
                  const unsigned int *fail, unsigned int *arena_n, unsigned int *range)
 {
     const bool bad = (*fail & 1u) != 0u;          // (the bits above count skipped tiles: kvq_validate_tiles)
+    // (the scan kernel's workgroups add to one of KVQ_STAGE_COPIES copies of the staged counters -- a thousand atomics on
+    // one word take 12 us at the end of every launch, an eighth of them a fraction of that: the copies are put together here)
     for (int i = threadIdx.x; i < KVQ_STAGE_SLOTS; i += blockDim.x) {
-        const unsigned long long v = stage[i];
+        unsigned long long v = 0;
+        for (int c = 0; c < KVQ_STAGE_COPIES; c++) {
+            const unsigned long long w = stage[(size_t)c * KVQ_STAGE_SLOTS + i];
+            v = i == KVQ_CTR_LONGEST_ ? (v > w ? v : w) : v + w;
+            stage[(size_t)c * KVQ_STAGE_SLOTS + i] = 0;
+        }
         if (v && !bad) { if (i == KVQ_CTR_LONGEST_) atomicMax(&ctr[i], v); else atomicAdd(&ctr[i], v); }
-        stage[i] = 0;
     }
     if (threadIdx.x == 0) {
         if (bad) *arena_n = range[0];
@@ -534,7 +539,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     // empty launches).  A batch that failed validation is left alone (it is redone as a whole), and so is one whose
     // skipped tiles hold more records than KVQ_REDO_CAP (kvq_dev_count raises its fail bit).  Their hits lie in the
     // batch's own range of the arena, closed below.
-    if (use_seeded && s->t->index && s->t->index->variant != 1) {
+    if (use_seeded) {
         const KvqRedo Rd(s->d_redo.p);
         unsigned int *const failw = s->d_fail + batch_no;
         const KvqSkippedTile *tiles = reinterpret_cast<const KvqSkippedTile *>(s->pool.d + s->cur_skip_at);

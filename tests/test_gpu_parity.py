@@ -21,10 +21,8 @@ from util import expected, check_against_expected
 
 pytestmark = pytest.mark.gpu
 
-# round 1's kernel (KVQ_KERNEL=v1, kept selectable) hands a batch with such a tile to the exhaustive kernels as a whole
-V1 = os.environ.get('KVQ_KERNEL') == 'v1'
-REDO_PATH = (dict(seeded=True, exhaustive=True, rescanned=True, tiles_rescanned=False) if V1 else
-             dict(seeded=True, exhaustive=True, rescanned=False, tiles_rescanned=True))
+# a tile that leaves records behind: only those go through the exhaustive kernels
+REDO_PATH = dict(seeded=True, exhaustive=True, rescanned=False, tiles_rescanned=True)
 
 CASES = cases.all_cases(big=True)
 
@@ -408,7 +406,7 @@ def test_seeded_and_exhaustive_kernels_agree_and_paths_are_as_expected(tmp_path)
     # a 9 kB record that starts 36 kB into the text outgrows the look-ahead of the tile that owns it
     # (a tile and its look-ahead span 40.8 kB): that tile's records are scanned again by the exhaustive kernels
     import os
-    if os.environ.get('KVQ_KERNEL') != 'v1' and not os.environ.get('KVQ_TILE'):   # (the bit-plane kernel, or another tile size, cuts the tiles elsewhere)
+    if not os.environ.get('KVQ_TILE'):   # (the bit-plane kernel, or another tile size, cuts the tiles elsewhere)
         want_path['long_reads_straddle'] = REDO_PATH   # (the one tile's records only)
     for name, wp in want_path.items():
         case = cases.by_name()[name.replace('_straddle', '')]
@@ -639,7 +637,7 @@ def test_one_long_record_costs_its_tile_not_the_batch():
         d.free()
     # (the redo costs a round trip to the host and a few small kernels; a rescan of the batch with the
     # exhaustive kernels took about 80 ms for these 300 k reads)
-    assert V1 or times['long'] < 2 * times['plain'] + 0.004, times
+    assert times['long'] < 2 * times['plain'] + 0.004, times
     s.close(); t.close()
 
 

@@ -24,7 +24,7 @@ names = (['P1 planes+bar', 'P1b nl list+bar', 'P2', 'P3a trim+bar', 'P3b filter'
          ['P0 store+bar', 'P1a scan+bar', 'P1b write+bar', 'P2', 'P3 desc+trim', 'P3 filter', 'P4a+P4b (own queue)', 'tile-end barrier'])
 tile_bytes = 28672 if os.environ.get('KVQ_KERNEL') == 'planes' else int(os.environ.get('KVQ_TILE', 39760))   # what kvq_choose_tile picks for 150 bp records
 tot = c.sum()
-wgs = int(os.environ.get('KVQ_WGS', 1024 if os.environ.get('KVQ_KERNEL') != 'v1' else 512))
+wgs = int(os.environ.get('KVQ_WGS', 1024))
 print('main kernel ms', r['main_kernel_ms'], 'tiles/WG', (n*rb/tile_bytes)/wgs)
 for nm, v in zip(names, c): print('%-16s %6.1f%%  %8.0f cycles/tile' % (nm, 100*v/tot, v/(n*rb/tile_bytes)))
 if os.environ.get('KVQ_KERNEL') != 'planes':
