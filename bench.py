@@ -292,7 +292,7 @@ def main():
                    'preheat_steps': max(0, args.preheat), 'steps_in_flight': depth},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                     'kernel': ('kvq_scan_pool' if os.environ.get('KVQ_KERNEL') == 'pool' else 'kvq_scan_bp') if any(table.seeded) and not args.exhaustive else 'kvq_match_all',
+                     'kernel': 'kvq_scan_bp' if any(table.seeded) and not args.exhaustive else 'kvq_match_all',
                      'launches_per_step': launches // max(1, args.steps), 'avg_launch_ms': main_avg_ms,
                      'algorithmic_bytes_per_launch': bytes_per_launch,
                      # (HIP events around everything a step enqueues; with several steps in flight that span also holds the

@@ -52,16 +52,12 @@ struct SeedTables {
     // entry: position in sequence (12) | sequence number (20) | table offset of the sequence (20) | its length (12)
     const uint64_t *ent_anc, *ent_all;
     const uint32_t *tab2;                     // the sequence table as 2-bit codes, 16 bases per word (kernels_bp.hip)
-    // the same tables once more in ONE allocation, addressed as words from one base (kernels_pool.hip: one pointer
-    // in scalar registers instead of six): start_anc at 0, start_all, tab2, then the 64-bit entries (even offsets)
-    const uint32_t *blob; uint32_t off_start_all, off_tab2, off_ent_anc, off_ent_all;
     int32_t stride;                           // read positions 0, stride, 2*stride, ... are looked up for anchors (2, 4 or 8)
 };
 
 struct SeedIndex {
-    int variant = 2;          // 2 = kvq_scan_bp (kernels_bp.hip, the default), 0 = kvq_scan_pool (KVQ_KERNEL=pool: the experiment of round 3)
     int stride = 2;           // anchor blocks sit at sequence offsets 8j + 0 .. 8j + stride - 1
-    DevBuf d_bm1, d_start_anc, d_start_all, d_ent_anc, d_ent_all, d_tab2, d_blob;
+    DevBuf d_bm1, d_start_anc, d_start_all, d_ent_anc, d_ent_all, d_tab2;
     SeedTables dev;
 };
 
@@ -82,8 +78,6 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     const int e = cfg.maxerrors;
     if (e < 0 || e > 6) return nullptr;
     const int need = (e + 1) * SK;
-    const char *kv = getenv("KVQ_KERNEL");
-    const int variant = (kv && !strcmp(kv, "pool")) ? 0 : 2;          // which kernel walks the text; the index is the same
     // every accepted alignment must be at least `need` long: class A/B overlaps
     // are >= minoverlap, class C lengths are min(readlength, sequence length)
     if (cfg.minoverlap < need || cfg.minreadlength < need) return nullptr;
@@ -118,13 +112,11 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
         for (int p = 0; p + SK <= len; p++) all.emplace_back(host_code8(q + p), hi | (uint64_t)p);
     }
     SeedIndex *ix = new SeedIndex();
-    ix->variant = variant; ix->stride = stride;
+    ix->stride = stride;
     std::vector<uint8_t> bm1(16384, 0);
-    std::vector<uint32_t> h_start[2]; std::vector<uint64_t> h_ent[2]; std::vector<uint32_t> h_tab2;
     auto upload = [&](std::vector<std::pair<uint32_t, uint64_t>> &v, int bit, DevBuf &st, DevBuf &en) -> bool {
         std::sort(v.begin(), v.end());
-        std::vector<uint32_t> &start = h_start[bit]; std::vector<uint64_t> &ent = h_ent[bit];
-        start.assign(65537, 0); ent.assign(v.size() + 1, 0);
+        std::vector<uint32_t> start(65537, 0); std::vector<uint64_t> ent(v.size() + 1, 0);
         for (size_t i = 0; i < v.size(); i++) {
             bm1[(size_t)bit * 8192 + (v[i].first >> 3)] |= (uint8_t)(1u << (v[i].first & 7));
             start[v[i].first + 1]++; ent[i] = v[i].second;
@@ -152,23 +144,6 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
             return nullptr;
         }
         ix->dev.tab2 = ix->d_tab2.as<uint32_t>();
-        h_tab2.swap(t2);
-    }
-    {
-        std::vector<uint32_t> blob;
-        auto put_words = [&](const uint32_t *w, size_t n) { const size_t at = blob.size(); blob.insert(blob.end(), w, w + n); while (blob.size() & 1) blob.push_back(0); return (uint32_t)at; };
-        put_words(h_start[0].data(), h_start[0].size());
-        ix->dev.off_start_all = put_words(h_start[1].data(), h_start[1].size());
-        ix->dev.off_tab2 = put_words(h_tab2.data(), h_tab2.size());
-        ix->dev.off_ent_anc = put_words(reinterpret_cast<const uint32_t *>(h_ent[0].data()), h_ent[0].size() * 2);
-        ix->dev.off_ent_all = put_words(reinterpret_cast<const uint32_t *>(h_ent[1].data()), h_ent[1].size() * 2);
-        blob.push_back(0); blob.push_back(0);
-        if (ix->d_blob.ensure(blob.size() * 4) != KVQ_OK || hipMemcpy(ix->d_blob.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            if (!kvq_error_code()) kvq_set_error(KVQ_ERR_DEVICE, "uploading the seed index failed");
-            kvq_seed_index_destroy(ix);
-            return nullptr;
-        }
-        ix->dev.blob = ix->d_blob.as<uint32_t>();
     }
     ix->dev.start_anc = ix->d_start_anc.as<uint32_t>(); ix->dev.start_all = ix->d_start_all.as<uint32_t>();
     ix->dev.ent_anc = ix->d_ent_anc.as<uint64_t>(); ix->dev.ent_all = ix->d_ent_all.as<uint64_t>();
@@ -179,7 +154,7 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
 void kvq_seed_index_destroy(SeedIndex *ix)
 {
     if (!ix) return;
-    DevBuf *b[] = { &ix->d_blob, &ix->d_tab2, &ix->d_bm1, &ix->d_start_anc, &ix->d_start_all, &ix->d_ent_anc, &ix->d_ent_all };
+    DevBuf *b[] = { &ix->d_tab2, &ix->d_bm1, &ix->d_start_anc, &ix->d_start_all, &ix->d_ent_anc, &ix->d_ent_all };
     for (DevBuf *x : b) x->release();
     delete ix;
 }

@@ -1,5 +1,5 @@
 // kvarq_amd/csrc/kvq_launch.hip -- enqueueing the fused seed-filter scan of one batch (whichever kernel walks the text:
-// kvq_scan_bp; kvq_scan_pool, round 3's experiment, with KVQ_KERNEL=pool)
+// kvq_scan_bp)
 #include "kvq_host.h"
 
 // ---------------------------------------------------------------------------
@@ -104,31 +104,13 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
                                                  kvq_scan_bp<2, 2, false>, kvq_scan_bp<4, 2, false>, kvq_scan_bp<8, 2, false>,
                                                  kvq_scan_bp<2, 2, true>, kvq_scan_bp<4, 2, true>, kvq_scan_bp<8, 2, true> };
         static const int lg_env = getenv("KVQ_LG") ? atoi(getenv("KVQ_LG")) : -2;
-        if (ix->variant == 2) {
-            int lg = -1;
-            if (s->rec_bytes >= 40u) {
-                const uint32_t n_full = TILE / s->rec_bytes + 1u;                    // records a full tile can own
-                if (n_full <= 128u && n_full > 64u) lg = 2;
-            }
-            if (lg_env >= -1) lg = lg_env == 2 ? 2 : -1;
-            hipLaunchKernelGGL(kernels_bp[(lg == 2 ? 6 : 0) + si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
-        } else {
-            // kvq_scan_pool: as few lanes per read as leave a lane at most 126 scores (two 63-bit chunks) -- fixed at compile
-            // time (1, 2 or 4 lanes: DPP inside a quad) when the records at the head of the text say so, otherwise
-            // the build that works the width out per tile; [mode][lanes][stride]
-#define PO_ROW(M) { { kvq_scan_pool<2, -1, M>, kvq_scan_pool<4, -1, M>, kvq_scan_pool<8, -1, M> }, { kvq_scan_pool<2, 0, M>, kvq_scan_pool<4, 0, M>, kvq_scan_pool<8, 0, M> }, \
-                  { kvq_scan_pool<2, 1, M>, kvq_scan_pool<4, 1, M>, kvq_scan_pool<8, 1, M> }, { kvq_scan_pool<2, 2, M>, kvq_scan_pool<4, 2, M>, kvq_scan_pool<8, 2, M> } }
-            static const BpKernel kernels_pool[3][4][3] = { PO_ROW(0), PO_ROW(1), PO_ROW(2) };
-#undef PO_ROW
-            int lg = -1;
-            if (s->rec_bytes >= 40u) {
-                const uint32_t q = s->rec_bytes > 25u ? (s->rec_bytes - 25u) / 2u : 1u;   // scores per record, about
-                lg = q <= 120u ? 0 : q <= 240u ? 1 : q <= 480u ? 2 : -1;                    // (a little room: reads vary)
-            }
-            if (lg_env >= -1) lg = lg_env <= 2 ? lg_env : -1;
-            const int mode = (dbg & 16u) ? 2 : dbg ? 1 : 0;
-            hipLaunchKernelGGL(kernels_pool[mode][lg + 1][si], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
+        int lg = -1;
+        if (s->rec_bytes >= 40u) {
+            const uint32_t n_full = TILE / s->rec_bytes + 1u;                    // records a full tile can own
+            if (n_full <= 128u && n_full > 64u) lg = 2;
         }
+        if (lg_env >= -1) lg = lg_env == 2 ? 2 : -1;
+        hipLaunchKernelGGL(kernels_bp[(lg == 2 ? 6 : 0) + si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
     }
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
     { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }              // (kvq_validate_tiles and what follows run beside the next scan)

@@ -3,7 +3,6 @@
 #include "kernels_general.hip"
 #include "kernels_seeded.hip"
 #include "kernels_bp.hip"
-#include "kernels_pool.hip"
 #include "kvq_launch.hip"
 #include "kernels_results.hip"
 #include "synth.hip"

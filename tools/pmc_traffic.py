@@ -22,7 +22,7 @@ def per_launch(root, counter, sub='kvq_scan_'):
 def main():
     fdir, wdir, reads, rb = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     import bench                                 # (source_sha256: the hash bench.py checks before it quotes this file)
-    kernel = 'kvq_scan_pool' if os.environ.get('KVQ_KERNEL') == 'pool' else 'kvq_scan_bp'
+    kernel = 'kvq_scan_bp'
     try:
         head = subprocess.check_output(['git', 'rev-parse', 'HEAD'], cwd=os.path.dirname(os.path.abspath(bench.__file__)), stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
