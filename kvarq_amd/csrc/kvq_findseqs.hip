@@ -350,7 +350,7 @@ public:
         const std::string &name = files_[next_++];
         fd_ = fopen(name.c_str(), "rb");
         if (!fd_) { kvq_set_error(KVQ_ERR_IO, "cannot open file"); return KVQ_ERR_IO; }
-        consumed_ = 0; file_done_ = false; opened_ = true; file_fpos0_ = fpos_;
+        consumed_ = 0; file_done_ = false; opened_ = true; file_fpos0_ = fpos_; serial_fpos0_ = fpos_;
         fseek(fd_, 0, SEEK_END); file_size_ = ftell(fd_); fseek(fd_, 0, SEEK_SET);
         gz_ = name.size() >= 3 && name.compare(name.size() - 3, 3, ".gz") == 0;     // by suffix (582)
         bgzf_ = false;
@@ -489,6 +489,7 @@ private:
             bgzf_ = false;
             bool no_member = false;
             z_.consumed = consumed_;
+            serial_fpos0_ = fpos_;                                                 // (the serial reader counts what IT produces: its error positions are relative to here)
             const int rc = z_.start(fd_, file_size_, boff_, &no_member);
             fd_ = nullptr;
             if (rc) { raise(z_); return -1; }
@@ -546,21 +547,24 @@ private:
     // an error met by a gzip reader, possibly in its own thread, raised in this one
     int raise(const GzSerial &z)
     {
-        if (z.err_at >= 0) kvq_set_error(z.err, "%s fpos=%ld", z.msg, (long)(file_fpos0_ + z.err_at));
+        if (z.err_at >= 0) kvq_set_error(z.err, "%s fpos=%ld", z.msg, (long)((&z == &z_ ? serial_fpos0_ : file_fpos0_) + z.err_at));
         else kvq_set_error(z.err, "%s", z.msg);
         return z.err;
     }
 
-    // inflated bytes a reader may run ahead of the stream: KVQ_GZ_AHEAD_MB, else a quarter of the free memory up to
-    // 16 GiB; none with nthreads == 1 (one worker was asked for)
-    static int64_t ahead_budget()
+    // inflated bytes a reader may run ahead of the stream, per reader (the current file's and the next file's run at once):
+    // KVQ_GZ_AHEAD_MB, else 256 MiB -- the scan takes 64 MiB at a time, a few batches of look-ahead keep it fed -- and never
+    // more than an eighth of the free memory; none with nthreads == 1 (one worker was asked for).  Worked out once per walk.
+    int64_t ahead_budget()
     {
+        if (ahead_budget_ >= 0) return ahead_budget_;
         kvq_config cfg; kvq_config_get(&cfg);
-        if (cfg.nthreads <= 1) return 0;
-        if (const char *e = getenv("KVQ_GZ_AHEAD_MB")) return (int64_t)atol(e) << 20;
+        if (cfg.nthreads <= 1) return ahead_budget_ = 0;
+        if (const char *e = getenv("KVQ_GZ_AHEAD_MB")) return ahead_budget_ = (int64_t)atol(e) << 20;
         const int64_t avail = (int64_t)sysconf(_SC_AVPHYS_PAGES) * sysconf(_SC_PAGESIZE);
-        return std::max<int64_t>(64ll << 20, std::min<int64_t>(avail / 4, 16ll << 30));
+        return ahead_budget_ = std::max<int64_t>(64ll << 20, std::min<int64_t>(avail / 8, 256ll << 20));
     }
+    int64_t ahead_budget_ = -1;
 
     // the file after the one just opened: when it is a plain .gz (not BGZF -- those are inflated block-parallel when
     // their turn comes), its reader starts now
@@ -594,6 +598,7 @@ private:
     std::vector<std::string> files_; size_t next_ = 0;
     FILE *fd_ = nullptr; bool gz_ = false, file_done_ = true;
     bool opened_ = false; int64_t file_fpos0_ = 0;                              // a file is open / the stream offset it began at
+    int64_t serial_fpos0_ = 0;                                                  // ... / the stream offset at which z_ started producing (behind a BGZF run: later than the file)
     GzSerial z_;                                                                // serial .gz reader in this thread ...
     std::unique_ptr<GzAhead> ahead_, ahead_next_; size_t ahead_next_for_ = 0;   // ... or in its own; the next file's, already running
     bool bgzf_ = false; int64_t boff_ = 0; std::vector<uint8_t> cbuf_;       // BGZF: next block's file offset, compressed run

@@ -37,7 +37,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     // (a process that keeps several scan objects is taken to overlap their work -- the next job's scan with the
     // last one's fold, ordering and copy: one CU in eight then keeps a workgroup slot free, so that those small
     // kernels run beside the persistent workgroups of the scan instead of behind them; tools: bench.py --pipeline)
-    static const uint32_t cus = kvq_device_cu_count();
+    const uint32_t cus = s->cus ? s->cus : (s->cus = kvq_device_cu_count());      // (of the device this scan object lives on: a process may use several)
     const uint32_t per_cu = 4u;
     const uint32_t grid_full = cus * per_cu, grid_shared = grid_full - cus / 8u;
     const uint32_t grid_cap = grid_env ? grid_env : (kvq_live_scans() > 1) ? grid_shared : grid_full;

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Regenerates the measurement artifacts under profiles/ on an MI355X box (run through gpurun from the
-# repo root: `gpurun --timeout 1200 -- 'bash tools/make_profiles.sh round2'`).  Everything is written
+# repo root: `gpurun --timeout 1200 -- "KVQ_GIT_HEAD=$(git rev-parse HEAD) bash tools/make_profiles.sh round3"`).  Everything is written
 # under gpurun_out/<tag>/ ; copy what is to be kept into profiles/ afterwards (the script prints the cp lines).
 # PMC passes are separate runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-round2}
+TAG=${1:-round3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py"
+B="python3 $R/bench.py --no-end-to-end"
 BP="$B --preheat 0"          # counter passes: every launch is counted, no need to heat the clocks
 step() { echo "== $1" >> $O/progress.txt; }
 
@@ -34,17 +34,22 @@ for d in 0 1 2 32; do
   echo "== KVQ_DBG=$d (0: whole kernel, 1: no verify, 2: no filter and verify, 32: front end only); 5 M reads per launch" >> $O/pmc_phases.txt
   python3 tools/pmc_sum.py $O/ph$d kvq_scan_ >> $O/pmc_phases.txt
 done
-step configs; bash tools/other_configs.sh > /dev/null 2>&1
+step configs; bash tools/other_configs.sh $TAG > /dev/null 2>&1
 step filerate; timeout -k 10 200 python3 tools/file_rate.py > $O/file_rate.txt 2>&1
+step filepath; KVQ_TIMING=1 timeout -k 10 200 python3 tools/r3_file.py 10000000 4 8 16 2>&1 | grep 'stream_batches\|plain file\|findseqs:' > $O/file_path.txt
+step long; ( timeout -k 10 200 python3 tools/realistic_bench.py 3000000; timeout -k 10 200 python3 tools/realistic_bench.py 3000000 100000 ) > $O/long_reads.txt 2>&1
+step probes; bash tools/r3_probe_ablation.sh > $O/probe_ablation.txt 2>&1
+step sizes; bash tools/r3_sizes.sh > $O/kernel_time_by_size.txt 2>&1
+step occ; bash tools/r3_occ.sh v2 > $O/time_by_occupancy.txt 2>&1
 step clock; bash tools/clock_pmc.sh $TAG/clk > $O/clock.txt 2>&1
 step ubench
 ( cd tools/ubench && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o valu_rate valu_rate.hip 2>/dev/null && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o issue_rate issue_rate.hip 2>/dev/null
   timeout -k 10 120 ./valu_rate > $O/valu_rate.txt 2>&1 && timeout -k 10 120 ./issue_rate > $O/issue_rate.txt 2>&1 )
 # the bench line last: it quotes the traffic file made above (same sources)
-step bench;  cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json; timeout -k 10 400 python3 bench.py > $O/bench_n1.json 2> $O/bench.err
-timeout -k 10 400 python3 bench.py --pipeline 1 --no-cpu-baseline > $O/bench_n1_pipeline1.json 2>> $O/bench.err
+step bench;  cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json; timeout -k 10 500 python3 bench.py > $O/bench_n1.json 2> $O/bench.err
+timeout -k 10 400 python3 bench.py --pipeline 1 --no-cpu-baseline --no-end-to-end > $O/bench_n1_pipeline1.json 2>> $O/bench.err
 step done
-for f in bench_n1.json bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt clock.txt valu_rate.txt issue_rate.txt; do
+for f in bench_n1.json bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt file_path.txt long_reads.txt probe_ablation.txt kernel_time_by_size.txt time_by_occupancy.txt clock.txt valu_rate.txt issue_rate.txt; do
   echo "cp gpurun_out/$TAG/$f profiles/${TAG}_$f"
 done
 cat $O/bench_n1.json
