@@ -379,6 +379,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     // for its text meets another's arithmetic: workgroup b sits in slot b / 256 of its compute unit under round-robin dispatch)
     if (const uint32_t stg = bp_args(A_)->pad_) { for (uint32_t i = 0; i < (blockIdx.x >> 8) * stg; i++) __builtin_amdgcn_s_sleep(127); }
     if constexpr (STAMPS) rt_pro = __builtin_amdgcn_s_memrealtime();
+    unsigned long long *const ctr_stamps = bp_args(A_)->P.ctr + KVQ_CTR_RL_ + 924;      // (instrumented build only; copy 0 of the staged counters)
     const uint32_t addk = (0x80u - amin) * 0x01010101u;
     uint32_t tiles_done = 0;
     // The barrier that ends a tile stands at the top of the next one, BEHIND the issue of that tile's loads:
@@ -418,6 +419,8 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         }
         // everyone is done with the last tile's planes; its loose ends
         __syncthreads();
+        unsigned long long sub_t0 = 0, sub_t1 = 0;
+        if constexpr (STAMPS) sub_t0 = __builtin_amdgcn_s_memtime();          // (instrumented build: the first phase in three parts -- the wait at this barrier, the wait for the text, P0 + the scan)
         if (g_done != 0xFFFFFFFFu) {
             if (tid == 0 && S.fallback) { atomicOr(&bp_args(A_)->tile_report[g_done], TR_FLAG_FALLBACK); S.fallback = 0; }
         }
@@ -448,6 +451,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 }
             }
         }
+        if constexpr (STAMPS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sub_t1 = __builtin_amdgcn_s_memtime(); }
         KVQ_MARK("P0 vectors");
         {
             const uint32_t pa = 2u * wv, ca = 4u * wv;
@@ -479,6 +483,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         const uint32_t incl = kvq_wave_incl_scan(cnt);
         if (lane == 63) S.wtot[wave] = incl;
         KVQ_MARK("P0 scan end");
+        if constexpr (STAMPS) { if (tid == 0) { atomicAdd(&ctr_stamps[0], sub_t0 - stamp_t); atomicAdd(&ctr_stamps[1], sub_t1 - sub_t0); } }
         BSTAMP(0);
         __syncthreads();
         KVQ_MARK("P1b");

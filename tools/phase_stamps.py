@@ -27,6 +27,8 @@ tot = c.sum()
 wgs = int(os.environ.get('KVQ_WGS', 1024))
 print('main kernel ms', r['main_kernel_ms'], 'tiles/WG', (n*rb/tile_bytes)/wgs)
 for nm, v in zip(names, c): print('%-16s %6.1f%%  %8.0f cycles/tile' % (nm, 100*v/tot, v/(n*rb/tile_bytes)))
+x = r['counters'][4+924:4+926].astype(np.float64) / (n*rb/tile_bytes)
+print('of the first phase: wait at the tile-top barrier %.0f, wait for the text (vmcnt) %.0f cycles/tile; the rest is P0 and the newline scan' % (x[0], x[1]))
 if os.environ.get('KVQ_KERNEL') != 'planes':
     w = r['counters'][4+908:4+916].astype(np.float64) / (n*rb/tile_bytes)
     print('P3+P4 cycles/tile by wave:', ' '.join('%.0f' % v for v in w))
