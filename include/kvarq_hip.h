@@ -285,6 +285,9 @@ int32_t kvq_memcpy_h2d(void *d, const void *h, int64_t nbytes);
 int32_t kvq_memcpy_d2h(void *h, const void *d, int64_t nbytes);
 int32_t kvq_memset_d(void *d, int32_t value, int64_t nbytes);
 int32_t kvq_device_synchronize(void);
+/* Device and pinned blocks of destroyed scans and tables are kept for the next ones (at most 2 GiB + 512 MiB;
+ * KVQ_BLOCK_CACHE=0 turns that off): this hands them back to the driver.  Nothing needs calling it. */
+void    kvq_release_cached(void);
 
 /* records first..first+n-1 of the synthetic FastQ stream of SURVEY 8(d)
  * (kvarq_amd/synth.py is the byte-identical numpy statement) written to

@@ -99,6 +99,7 @@ PROTOTYPES = {
     'kvq_memcpy_d2h': (i32, [vp, vp, i64]),
     'kvq_memset_d': (i32, [vp, i32, i64]),
     'kvq_device_synchronize': (i32, []),
+    'kvq_release_cached': (None, []),
     'kvq_synth_reads_device': (i32, [vp, i64, i64, i32, u64, vp, i64]),
     'kvq_synth_reads_host': (None, [vp, i64, i64, i32, u64, vp, i64]),
     'kvq_synth_genome_host': (None, [vp, i64, u64]),

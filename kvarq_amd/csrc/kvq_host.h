@@ -35,7 +35,7 @@ struct DevBuf {
 // per-batch tables (chunk offsets, tile maps): pinned host memory mirrored by device
 // memory, bump-allocated so that a batch can be enqueued without waiting for the previous one
 struct TablePool {
-    uint8_t *h = nullptr, *d = nullptr; size_t cap = 0, used = 0;
+    uint8_t *h = nullptr, *d = nullptr; size_t cap = 0, used = 0, h_cap = 0, d_cap = 0;
     int reserve(size_t bytes, hipStream_t stream);   // makes room (may synchronise the stream when growing)
     size_t take(size_t bytes) { const size_t at = used; used += (bytes + 255) & ~(size_t)255; return at; }
     void release();
@@ -93,7 +93,7 @@ struct kvq_scan {
     hipStream_t stream = nullptr;
     bool force_exhaustive = false;
     // counters
-    unsigned long long *d_ctr = nullptr; bool own_ctr = false;
+    unsigned long long *d_ctr = nullptr; bool own_ctr = false; DevBuf d_ctr_own;
     std::vector<int64_t> h_ctr;
     // per-batch scratch
     uint32_t cus = 0;                  // compute units of the scan's device (asked once)
@@ -138,7 +138,7 @@ struct kvq_scan {
     uint8_t *pin_res = nullptr;                   // where the result arrays start inside pin (behind the counters)
     size_t spec_bytes = 1u << 20;                 // result bytes fetched together with the counters, before their number is known (the last scan's)
     uint8_t *pin = nullptr; size_t pin_cap = 0;   // pinned landing buffer of finish: the result arrays, then the counters
-    uint8_t *pin_small = nullptr;                 // pinned landing buffer for the scan's small words and fail flags
+    uint8_t *pin_small = nullptr; size_t pin_small_cap = 0;   // pinned landing buffer for the scan's small words and fail flags
     KvqResultLayout res;                          // where the arrays sit inside pin
     uint64_t n_hits = 0;
     bool finished = false;

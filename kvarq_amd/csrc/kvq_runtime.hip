@@ -50,12 +50,61 @@ extern "C" const char *kvq_version(void) { return "kvarq_hip 0.1 (gfx950)"; }
 // device plumbing
 // ---------------------------------------------------------------------------
 
+// Blocks a destroyed scan or table gives back are kept for the next one (per device, up to a bound): a scan's dozen
+// hipMalloc / hipFree calls and its pinned buffers cost about 15 ms a scan, more than the kernels of a 3 GB file.
+// A block in the cache is idle: whoever releases one has waited for the work that used it (kvq_scan_destroy,
+// kvq_table_destroy); a buffer that grows while its scan is running goes back to the driver instead (hipFree waits).
+namespace {
+struct BlockCache {
+    struct E { void *p; size_t cap; int dev; };
+    std::mutex m; std::vector<E> v; size_t bytes = 0; const size_t max_bytes; const bool host;
+    BlockCache(size_t mb, bool h) : max_bytes(mb), host(h) {}
+    void *take(size_t n, size_t *cap)
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> l(m);
+        size_t best = v.size();
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i].dev == dev && v[i].cap >= n && v[i].cap <= 2 * n + (1u << 20) && (best == v.size() || v[i].cap < v[best].cap)) best = i;
+        if (best == v.size()) return nullptr;
+        void *p = v[best].p; *cap = v[best].cap; bytes -= v[best].cap;
+        v.erase(v.begin() + (long)best);
+        return p;
+    }
+    bool put(void *p, size_t cap)
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> l(m);
+        if (cap > max_bytes / 2 || v.size() >= 256) return false;
+        while (bytes + cap > max_bytes && !v.empty()) {          // the oldest blocks make room
+            if (host) (void)hipHostFree(v[0].p); else (void)hipFree(v[0].p);
+            bytes -= v[0].cap; v.erase(v.begin());
+        }
+        v.push_back({ p, cap, dev }); bytes += cap;
+        return true;
+    }
+    void drop()
+    {
+        std::lock_guard<std::mutex> l(m);
+        for (auto &e : v) { if (host) (void)hipHostFree(e.p); else (void)hipFree(e.p); }
+        v.clear(); bytes = 0;
+    }
+};
+static bool cache_on() { static const bool on = !(getenv("KVQ_BLOCK_CACHE") && getenv("KVQ_BLOCK_CACHE")[0] == '0'); return on; }
+static BlockCache g_dev_blocks((size_t)2 << 30, false), g_pin_blocks((size_t)512 << 20, true);
+}
+
+// give the cached blocks back to the driver (a host that wants the memory; nothing needs calling this)
+extern "C" void kvq_release_cached(void) { g_dev_blocks.drop(); g_pin_blocks.drop(); }
+
 int DevBuf::ensure(size_t n)
 {
     if (n <= cap && p) return KVQ_OK;
     size_t want = n + n / 4 + 256;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (cache_on()) { size_t c = 0; if (void *q = g_dev_blocks.take(n + 256, &c)) { p = q; cap = c; return KVQ_OK; } }
     hipError_t e = hipMalloc(&p, want);
+    if (e == hipErrorOutOfMemory && g_dev_blocks.bytes) { g_dev_blocks.drop(); e = hipMalloc(&p, want); }
     if (e != hipSuccess) {
         p = nullptr;
         kvq_set_error(e == hipErrorOutOfMemory ? KVQ_ERR_MEMORY : KVQ_ERR_DEVICE, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
@@ -64,7 +113,18 @@ int DevBuf::ensure(size_t n)
     cap = want;
     return KVQ_OK;
 }
-void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+void DevBuf::release() { if (p && !(cache_on() && g_dev_blocks.put(p, cap))) (void)hipFree(p); p = nullptr; cap = 0; }
+
+// pinned host memory through the same kind of cache (*cap: what the block holds, at least n)
+static void *pinned_take(size_t n, size_t *cap)
+{
+    if (cache_on()) if (void *q = g_pin_blocks.take(n, cap)) return q;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return nullptr;
+    *cap = n;
+    return p;
+}
+static void pinned_give(void *p, size_t cap) { if (p && !(cache_on() && g_pin_blocks.put(p, cap))) (void)hipHostFree(p); }
 
 int TablePool::reserve(size_t bytes, hipStream_t stream)
 {
@@ -74,23 +134,24 @@ int TablePool::reserve(size_t bytes, hipStream_t stream)
     // (tile reports, lists of skipped tiles: found again by their offsets) moves over
     if (stream) KVQ_HIP(hipStreamSynchronize(stream));
     const size_t want = std::max<size_t>(2 * cap, std::max<size_t>(used + bytes, (size_t)8 << 20));
-    uint8_t *nh = nullptr, *nd = nullptr;
-    if (hipHostMalloc((void **)&nh, want, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&nd, want) != hipSuccess) {
-        if (nh) (void)hipHostFree(nh);
+    size_t hcap = 0; uint8_t *nh = (uint8_t *)pinned_take(want, &hcap);
+    DevBuf nd;
+    if (!nh || nd.ensure(want) != KVQ_OK) {
+        if (nh) pinned_give(nh, hcap);
         kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate %zu bytes of batch tables", want);
         return KVQ_ERR_MEMORY;
     }
-    if (used) { memcpy(nh, h, used); KVQ_HIP(hipMemcpy(nd, d, used, hipMemcpyDeviceToDevice)); }
+    if (used) { memcpy(nh, h, used); KVQ_HIP(hipMemcpy(nd.p, d, used, hipMemcpyDeviceToDevice)); }
     const size_t keep = used;
     release();
-    h = nh; d = nd; cap = want; used = keep;
+    h = nh; h_cap = hcap; d = (uint8_t *)nd.p; d_cap = nd.cap; cap = want; used = keep;
     return KVQ_OK;
 }
 void TablePool::release()
 {
-    if (h) (void)hipHostFree(h);
-    if (d) (void)hipFree(d);
-    h = d = nullptr; cap = used = 0;
+    if (h) pinned_give(h, h_cap);
+    if (d) { DevBuf b; b.p = d; b.cap = d_cap; b.release(); }
+    h = d = nullptr; cap = used = 0; h_cap = d_cap = 0;
 }
 
 extern "C" int32_t kvq_device_count(void)
@@ -166,6 +227,7 @@ extern "C" kvq_table *kvq_table_create(const uint8_t *const *seqs, const int32_t
 extern "C" void kvq_table_destroy(kvq_table *t)
 {
     if (!t) return;
+    (void)hipDeviceSynchronize();      // (its blocks go to the cache, not through hipFree: nothing may still be reading them)
     if (t->index) kvq_seed_index_destroy(t->index);
     t->d_tab.release(); t->d_off.release(); t->d_exh.release(); t->d_all.release(); t->d_seeded.release();
     delete t;
@@ -289,8 +351,8 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     }
     if (d_counters) { s->d_ctr = (unsigned long long *)d_counters; s->own_ctr = false; }
     else {
-        if (hipMalloc((void **)&s->d_ctr, (size_t)t->ctr_len * 8) != hipSuccess) { kvq_set_error(KVQ_ERR_MEMORY, "hipMalloc(counters) failed"); kvq_scan_destroy(s); return nullptr; }
-        s->own_ctr = true;
+        if (s->d_ctr_own.ensure((size_t)t->ctr_len * 8) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
+        s->d_ctr = s->d_ctr_own.as<unsigned long long>(); s->own_ctr = true;
     }
     if (s->d_small.ensure(SMALL_BYTES) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     if (s->d_covdiff.ensure(((size_t)t->bases + (size_t)t->nseq + 1) * 8) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
@@ -304,9 +366,14 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     if (ensure_arena(s, 1u << 20, 64ull << 20) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     if (s->d_redo.ensure(KvqRedo::bytes()) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     s->pin_cap = (size_t)t->ctr_len * 8 + (4u << 20);
-    if (hipHostMalloc((void **)&s->pin_small, 64 + 4 * (size_t)KVQ_MAX_BATCHES + 512, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&s->pin, s->pin_cap, hipHostMallocDefault) != hipSuccess) {
-        kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); kvq_scan_destroy(s); return nullptr;
+    {
+        const size_t small_b = 64 + 4 * (size_t)KVQ_MAX_BATCHES + 512;
+        size_t c = 0;
+        s->pin_small = (uint8_t *)pinned_take(small_b, &c); s->pin_small_cap = c;
+        s->pin = (uint8_t *)pinned_take(s->pin_cap, &c);
+        if (s->pin) s->pin_cap = c;
+        if (!s->pin_small || !s->pin) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); kvq_scan_destroy(s); return nullptr; }
+        memset(s->pin_small, 0, small_b);
     }
     memset(s->pin, 0, s->pin_cap < (1u << 20) ? s->pin_cap : (1u << 20));
     s->res = kvq_result_layout(0, 0);
@@ -362,9 +429,10 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     g_live_scans--;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     drop_events(s, true);
-    if (s->own_ctr && s->d_ctr) (void)hipFree(s->d_ctr);
-    if (s->pin) (void)hipHostFree(s->pin);
-    if (s->pin_small) (void)hipHostFree(s->pin_small);
+    s->d_ctr_own.release();
+    if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+    if (s->pin) pinned_give(s->pin, s->pin_cap);
+    if (s->pin_small) pinned_give(s->pin_small, s->pin_small_cap);
     for (int i = 0; i < 2; i++) if (s->ev_copy[i]) (void)hipEventDestroy(s->ev_copy[i]);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
@@ -601,6 +669,8 @@ extern "C" int32_t kvq_scan_device(kvq_scan *s, const void *d_data, int64_t nbyt
 // follow each other without a gap, kernels run beside them, and the host is back reading the next batch while both go on.
 // Settling a batch = waiting for its kernels and looking at its fail word: when its seed-filter pass failed validation it is
 // scanned again, exhaustively, while its text is still in its staging buffer.
+static DevBuf &stage_of(kvq_scan *s, int slot) { return slot == 0 ? s->d_stage : s->d_stage_b; }
+
 static int settle_in_flight(kvq_scan *s)
 {
     KVQ_HIP(hipStreamSynchronize(s->stream));
@@ -616,7 +686,7 @@ static int settle_in_flight(kvq_scan *s)
     Batch again = s->batches[b]; again.is_redo = true;
     s->batches.push_back(again);
     s->path_bits |= 4;
-    int rc = run_batch(s, (s->run_slot ? s->d_stage_b : s->d_stage).as<uint8_t>(), again.nbytes, again.chunk_off.data(), (int64_t)again.chunk_off.size() - 1,
+    int rc = run_batch(s, stage_of(s, s->run_slot).as<uint8_t>(), again.nbytes, again.chunk_off.data(), (int64_t)again.chunk_off.size() - 1,
                        again.fpos_base, s->batches.size() - 1, true);
     if (rc) return rc;
     KVQ_HIP(hipStreamSynchronize(s->stream));
@@ -629,7 +699,7 @@ static int launch_copied(kvq_scan *s)
     if (!s->copied_pending) return KVQ_OK;
     s->copied_pending = false;
     const int slot = s->copied_slot;
-    DevBuf &stage = slot ? s->d_stage_b : s->d_stage;
+    DevBuf &stage = stage_of(s, slot);
     s->pool.used = 0;
     *reinterpret_cast<unsigned int *>(s->pin_small + 40) = 0;    // "speculation failed" of the batch about to be enqueued
     KVQ_HIP(hipStreamWaitEvent(s->stream, s->ev_copy[slot], 0));
@@ -663,8 +733,8 @@ extern "C" int32_t kvq_scan_host_async(kvq_scan *s, const void *h_data, int64_t 
     if ((rc = check_batch(h_data, nbytes, chunk_off, nchunks, s->batches.size() + (s->copied_pending ? 1u : 0u), false))) return rc;
     if ((rc = settle_in_flight(s))) return rc;                     // the batch whose kernels ran while the caller read this one
     if ((rc = launch_copied(s))) return rc;                        // the batch handed over last call: its text has arrived meanwhile
-    const int slot = s->run_slot ^ 1;                              // (the buffer of the batch settled just now, or one never used)
-    DevBuf &stage = slot ? s->d_stage_b : s->d_stage;
+    const int slot = s->run_slot == 0 ? 1 : 0;                     // (the buffer of the batch settled just now, or one never used)
+    DevBuf &stage = stage_of(s, slot);
     if ((rc = stage.ensure((size_t)nbytes + 64))) return rc;
     if (!s->copy_stream) KVQ_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) if (!s->ev_copy[i]) KVQ_HIP(hipEventCreateWithFlags(&s->ev_copy[i], hipEventDisableTiming));
@@ -792,11 +862,11 @@ static int finish_once(kvq_scan *s)
         if (ctr_b + L.total > s->pin_cap) {
             // (a larger landing buffer: the counters, already there, move over)
             const size_t want = (ctr_b + L.total) * 5 / 4 + (1 << 20);
-            uint8_t *np = nullptr;
-            if (hipHostMalloc((void **)&np, want, hipHostMallocDefault) != hipSuccess) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); return KVQ_ERR_MEMORY; }
+            size_t got = 0; uint8_t *np = (uint8_t *)pinned_take(want, &got);
+            if (!np) { kvq_set_error(KVQ_ERR_MEMORY, "cannot allocate memory for results"); return KVQ_ERR_MEMORY; }
             memcpy(np, s->pin, ctr_b);
-            (void)hipHostFree(s->pin);
-            s->pin = np; s->pin_cap = want; spec = 0;
+            pinned_give(s->pin, s->pin_cap);
+            s->pin = np; s->pin_cap = got; spec = 0;
         }
         bool refetch = L.total > spec;
         if (n_hits && (no_buckets || st.crowded)) {

@@ -13,6 +13,7 @@ The scan itself runs only on the GPU: without the library or without a device
 ``findseqs`` raises, it never falls back to a CPU implementation.
 """
 import collections
+import numpy as np
 import ctypes as C
 
 from . import _lib
@@ -110,6 +111,8 @@ def findseqs(fname, sequences):
     fname: file name or sequence of file names (plain or ``.gz``), scanned as one
     stream; sequences: sequence of strings.  Returns ``{'hits': tuple of Hit,
     'stats': dict as stats(), 'hitseqs': list of hit base strings}``."""
+    import os, time
+    t_in = time.perf_counter()
     L = _lib.lib()
     if isinstance(fname, (str, bytes)):
         fnames = [fname]
@@ -143,31 +146,43 @@ def findseqs(fname, sequences):
     lens = (C.c_int32 * max(1, n))(*[len(s) for s in bseqs])
 
     # ctypes releases the GIL for the duration of the call (workhorse.c:1377-1408)
+    t_0 = time.perf_counter()
     h = L.kvq_findseqs(farr, len(bfiles), sarr, lens, n)
+    t_1 = time.perf_counter()
     try:
         code, _ = _lib.last_error()
         if not h or code:
             _raise_last()
         nh = L.kvq_scan_n_hits(h)
-        seq_nr, fpos = L.kvq_scan_hit_seq_nr(h), L.kvq_scan_hit_file_pos(h)
-        spos, length, rl = L.kvq_scan_hit_seq_pos(h), L.kvq_scan_hit_length(h), L.kvq_scan_hit_readlength(h)
-        hits = tuple(Hit(seq_nr[i], fpos[i], spos[i], length[i], rl[i]) for i in range(nh))
-        off = L.kvq_scan_hitseq_offsets(h)
+        # (the arrays become Python objects in bulk: one ctypes index operation per field of every hit cost more
+        # than the scan of a 3 GB file)
+        def col(ptr, count):
+            return np.ctypeslib.as_array(ptr, shape=(count,)).tolist() if count else []
+        hits = tuple(map(Hit, col(L.kvq_scan_hit_seq_nr(h), nh), col(L.kvq_scan_hit_file_pos(h), nh), col(L.kvq_scan_hit_seq_pos(h), nh),
+                         col(L.kvq_scan_hit_length(h), nh), col(L.kvq_scan_hit_readlength(h), nh)))
+        off = col(L.kvq_scan_hitseq_offsets(h), nh + 1)
         blob = C.string_at(L.kvq_scan_hitseq_blob(h), off[nh]) if nh else b''
-        hitseqs = [blob[off[i]:off[i + 1]] for i in range(nh)]
         if as_str:
-            hitseqs = [x.decode('latin-1') for x in hitseqs]
-        ctr = L.kvq_scan_counters(h)
+            blob = blob.decode('latin-1')
+        hitseqs = [blob[a:b] for a, b in zip(off, off[1:])]
         # counters layout (include/kvarq_hip.h): 4 scalars, readlengths[1024], nseqhits[n], nseqbasehits[n], ...
         o_hits = _lib.CTR_READLENGTHS + _lib.MAX_READLENGTH
+        ctr = col(L.kvq_scan_counters(h), o_hits + 2 * n)
         st = _stats_dict(
-            [ctr[_lib.CTR_READLENGTHS + i] for i in range(_lib.MAX_READLENGTH)], ctr[_lib.CTR_LONGEST] - 1,
-            [ctr[o_hits + n + i] for i in range(n)], [ctr[o_hits + i] for i in range(n)],
+            ctr[_lib.CTR_READLENGTHS:o_hits], ctr[_lib.CTR_LONGEST] - 1,
+            ctr[o_hits + n:o_hits + 2 * n], ctr[o_hits:o_hits + n],
             L.kvq_scan_parsed(h), L.kvq_scan_total(h), _sigints(), ctr[_lib.CTR_RECORDS])
+        if os.environ.get('KVQ_TIMING'):
+            import sys
+            sys.stderr.write('engine.findseqs: arguments %.1f ms, library %.1f ms, results as Python objects %.1f ms\n' % ((t_0 - t_in) * 1e3, (t_1 - t_0) * 1e3, (time.perf_counter() - t_1) * 1e3))
         return {'hits': hits, 'stats': st, 'hitseqs': hitseqs}
     finally:
         if h:
+            t_f = time.perf_counter()
             L.kvq_findseqs_free(h)
+            if os.environ.get('KVQ_TIMING'):
+                import sys
+                sys.stderr.write('engine.findseqs: free %.1f ms\n' % ((time.perf_counter() - t_f) * 1e3))
 
 
 def _sigints():

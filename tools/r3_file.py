@@ -16,5 +16,6 @@ for nt in nts:
     engine.config(maxerrors=2, minoverlap=25, minreadlength=25, Amin='.', nthreads=nt)
     for rep in range(3):
         t0 = time.perf_counter(); r = engine.findseqs(path, seqs); dt = time.perf_counter() - t0
+        if os.environ.get('KVQ_TIMING'): sys.stderr.write('whole call %.1f ms\n' % (dt * 1e3))
     print('plain file %.2f GB  nthreads=%2d  %.3f s  %.1f M reads/s  %.2f GB/s  hits=%d' % (n * rb / 1e9, nt, dt, n / dt / 1e6, n * rb / dt / 1e9, len(r['hits'])))
 os.remove(path)
