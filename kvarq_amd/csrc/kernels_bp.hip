@@ -916,3 +916,52 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         if (S.records) atomicAdd(&ctr[KVQ_CTR_RECORDS_], (unsigned long long)S.records);
     }
 }
+
+// kvq_trim_records' long score lines (declared in kernels_general.hip): lane l sums up scores [1024 r + 16 l, + 16) of
+// every KiB r as a Seg (bp_runs64), an ordered tree merge over the wave gives the KiB's Seg, the KiBs are merged in turn
+__device__ void kvq_long_line_run(const uint8_t *line, uint32_t Q, int amin, int lane, int &best, uint32_t &best_start)
+{
+    Seg all; all.beg = 0; all.len = 0; all.pre = 0; all.suf = 0; all.best = 0; all.bstart = 0;
+    for (uint32_t r0 = 0; r0 < Q; r0 += 4096u) {
+        uint32_t w[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t o = r0 + 1024u * (uint32_t)r + 16u * (uint32_t)lane;
+            const uint32_t oo = o + 16u <= Q + 1u ? o : (Q + 1u >= 16u ? Q + 1u - 16u : 0u);      // (loads stay inside the line and its newline; every load is issued)
+#pragma unroll
+            for (int d = 0; d < 4; d++) __builtin_memcpy(&w[r][d], line + oo + 4u * d, 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t row = r0 + 1024u * (uint32_t)r;
+            if (row >= Q) break;
+            const uint32_t o = row + 16u * (uint32_t)lane;
+            const uint32_t oo = o + 16u <= Q + 1u ? o : (Q + 1u >= 16u ? Q + 1u - 16u : 0u);
+            const int n = o < Q ? (Q - o < 16u ? (int)(Q - o) : 16) : 0;
+            uint32_t m = 0;
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) m |= (uint32_t)((int)(int8_t)(w[r][d] >> (8 * b)) >= amin) << (4 * d + b);
+            // (a vector that was loaded from further down -- the line's last one -- is shifted into place)
+            const uint32_t shift = o - oo;                                 // 0 unless the vector was moved
+            m = shift < 16u ? m >> shift : 0u;
+            m &= n > 0 ? (1u << n) - 1u : 0u;
+            Seg sg; sg.beg = (int)o; sg.len = n;
+            int bs;
+            bp_runs64((uint64_t)m, n, 0u, sg.pre, sg.suf, sg.best, bs);
+            sg.bstart = (int)o + bs;
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                Seg B;
+                B.len = __shfl_xor(sg.len, (int)d, 64); B.pre = __shfl_xor(sg.pre, (int)d, 64); B.suf = __shfl_xor(sg.suf, (int)d, 64);
+                B.best = __shfl_xor(sg.best, (int)d, 64); B.bstart = __shfl_xor(sg.bstart, (int)d, 64); B.beg = 0;
+                if (((uint32_t)lane & d) == 0) sg = seg_merge(sg, B);
+            }
+            Seg R;
+            R.beg = (int)row; R.len = __shfl(sg.len, 0, 64); R.pre = __shfl(sg.pre, 0, 64); R.suf = __shfl(sg.suf, 0, 64);
+            R.best = __shfl(sg.best, 0, 64); R.bstart = __shfl(sg.bstart, 0, 64);
+            all = (row == 0u) ? R : seg_merge(all, R);
+        }
+    }
+    best = all.best; best_start = (uint32_t)all.bstart;
+}

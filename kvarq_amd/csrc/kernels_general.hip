@@ -144,6 +144,20 @@ __device__ __forceinline__ uint32_t kvq_dev_count(uint32_t n, const KvqDevCount 
     return v;
 }
 
+// sixteen bytes of text -> bit i: byte i is a newline
+__device__ __forceinline__ uint32_t kvq_newlines16(const uint4 v)
+{
+    const uint32_t x[4] = { v.x, v.y, v.z, v.w };
+    uint32_t m = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t t = x[d] ^ 0x0A0A0A0Au;
+        const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);     // 0x80 in every byte that is '\n' (exact)
+        m |= ((((z >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * d);
+    }
+    return m;
+}
+
 extern "C" __global__ void __launch_bounds__(256)
 kvq_collect_skipped(const uint8_t *__restrict__ data, const KvqSkippedTile *__restrict__ tiles, uint32_t ntiles_, KvqDevCount dc,
                     uint32_t *__restrict__ nl4, uint32_t *__restrict__ rec_start, unsigned int *__restrict__ rec_count, uint32_t rec_cap)
@@ -155,37 +169,44 @@ kvq_collect_skipped(const uint8_t *__restrict__ data, const KvqSkippedTile *__re
     uint32_t idx = T.seen;                       // number (within the chunk) of the next newline met
     bool collecting = T.first != 0u;             // tile 0: the chunk's first record
     uint32_t rstart = T.a, cnt = 0, nlb[4] = { 0, 0, 0, 0 };
-    for (uint32_t p4 = T.own_begin; p4 < T.b; p4 += 1024u) {
+    // 4 KiB a round: four 16-byte vectors a lane, all four loads in flight (a record of thousands of bytes is a chain of
+    // memory round trips otherwise; the text is 16-byte aligned, check_batch), the newlines of a vector as a 16-bit mask;
+    // the wave then walks the masks that are not empty, in text order
+    const uint32_t last_v = (T.b - 1u) & ~15u;
+    for (uint32_t p4 = T.own_begin & ~15u; p4 < T.b; p4 += 4096u) {
         if (p4 >= T.own_end && !collecting) break;
-        // (sixteen loads in flight: a record of thousands of bytes is a chain of memory round trips otherwise)
-        // (every load is issued whatever its place: a load behind a branch is waited for before the next one goes out)
-        uint8_t by[16]; bool nl[16];
+        uint32_t m16[4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t q = p4 + 64u * (uint32_t)k + (uint32_t)lane;
-            by[k] = data[q < T.b ? q : T.b - 1u];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t q = p4 + 1024u * (uint32_t)k + 16u * (uint32_t)lane;
+            const uint4 v = *reinterpret_cast<const uint4 *>(data + (q < T.b ? q : last_v));      // (every load is issued whatever its place: a load behind a branch is waited for before the next one goes out)
+            const uint32_t lo = q < T.own_begin ? (T.own_begin - q < 16u ? T.own_begin - q : 16u) : 0u;
+            const uint32_t hi = q < T.b ? (T.b - q < 16u ? T.b - q : 16u) : 0u;
+            m16[k] = hi > lo ? kvq_newlines16(v) & ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < 16; k++) nl[k] = p4 + 64u * (uint32_t)k + (uint32_t)lane < T.b && by[k] == '\n';
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t p = p4 + 64u * (uint32_t)k;
-            if (p >= T.b || (p >= T.own_end && !collecting)) break;
-            unsigned long long m = __ballot(nl[k]);
-            while (m) {                              // (the same for every lane: the mask is the wave's)
-                const uint32_t pos = p + (uint32_t)(__ffsll((long long)m) - 1); m &= m - 1ull;
-                if (collecting) {
-                    nlb[cnt++] = pos;
-                    if (cnt == 4u) {
-                        if (lane == 0) {
-                            const unsigned int r = atomicAdd(rec_count, 1u);
-                            if (r < rec_cap) { rec_start[r] = rstart; nl4[4 * (size_t)r] = nlb[0]; nl4[4 * (size_t)r + 1] = nlb[1]; nl4[4 * (size_t)r + 2] = nlb[2]; nl4[4 * (size_t)r + 3] = nlb[3]; }
+        for (int k = 0; k < 4; k++) {
+            const uint32_t row = p4 + 1024u * (uint32_t)k;
+            if (row >= T.b || (row >= T.own_end && !collecting)) break;
+            unsigned long long any = __ballot(m16[k] != 0u);
+            while (any) {                            // (the same for every lane: the mask is the wave's)
+                const int l = __ffsll((long long)any) - 1; any &= any - 1ull;
+                uint32_t mm = (uint32_t)__shfl((int)m16[k], l, 64);
+                while (mm) {
+                    const uint32_t pos = row + 16u * (uint32_t)l + (uint32_t)(__ffs((int)mm) - 1); mm &= mm - 1u;
+                    if (collecting) {
+                        nlb[cnt++] = pos;
+                        if (cnt == 4u) {
+                            if (lane == 0) {
+                                const unsigned int r = atomicAdd(rec_count, 1u);
+                                if (r < rec_cap) { rec_start[r] = rstart; nl4[4 * (size_t)r] = nlb[0]; nl4[4 * (size_t)r + 1] = nlb[1]; nl4[4 * (size_t)r + 2] = nlb[2]; nl4[4 * (size_t)r + 3] = nlb[3]; }
+                            }
+                            collecting = false;
                         }
-                        collecting = false;
                     }
+                    if ((idx & 3u) == 3u && pos < T.own_end) { collecting = true; rstart = pos + 1u; cnt = 0; }     // (an owned newline that ends a record: the next one starts behind it)
+                    idx++;
                 }
-                if ((idx & 3u) == 3u && pos < T.own_end) { collecting = true; rstart = pos + 1u; cnt = 0; }     // (an owned newline that ends a record: the next one starts behind it)
-                idx++;
             }
         }
     }
@@ -225,6 +246,11 @@ __device__ __forceinline__ void run_feed(RunState &st, uint64_t good, int nbits,
 }
 
 #define KVQ_TRIM_RPW 16   // records per wave
+// the longest run of scores >= amin among line[0 .. Q) (the byte behind it closes the last run), the first of equally long
+// ones, by all 64 lanes of a wave; the answer in every lane (kernels_bp.hip)
+__device__ void kvq_long_line_run(const uint8_t *line, uint32_t Q, int amin, int lane, int &best, uint32_t &best_start);
+#define KVQ_LONG_READ 1024  // (redo of skipped tiles) reads from here on are matched by a launch of their own
+#define KVQ_LONG_CAP 2048u  // ... at most so many of them (the rest stays with the ordinary ones)
 
 // one wave per record, KVQ_TRIM_RPW consecutive records per wave.
 // read_off[g] = batch offset of the first base of the trimmed read,
@@ -232,8 +258,13 @@ __device__ __forceinline__ void run_feed(RunState &st, uint64_t good, int nbits,
 extern "C" __global__ void __launch_bounds__(256)
 kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, uint32_t nrec_, KvqDevCount dc,
                  const uint32_t *__restrict__ nl4, const uint32_t *__restrict__ rec_start,
-                 uint32_t *__restrict__ read_off, int32_t *__restrict__ read_len, int32_t count, uint32_t rpw)
+                 uint32_t *__restrict__ read_off, int32_t *__restrict__ read_len, int32_t count, uint32_t rpw,
+                 unsigned int *__restrict__ long_count, uint32_t long_top)
 {
+    // long_count (the redo of skipped tiles only): a read of KVQ_LONG_READ bases or more goes to a list of its own, filled
+    // from read_off[long_top] / read_len[long_top] downwards, at most KVQ_LONG_CAP of them: the matcher is launched once for
+    // the many ordinary reads (a wave a read) and once for the few long ones (a read's sequences and alignments spread
+    // over hundreds of waves) -- one grid cannot serve both without the host knowing the numbers
     const uint32_t nrec = kvq_dev_count(nrec_, dc);
     if (nrec == 0) return;
     // rpw: consecutive records per wave (KVQ_TRIM_RPW for a batch of ordinary reads; 1 for the few, possibly very
@@ -263,9 +294,13 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
         // score line including its '\n': bytes [sscore, n3]
         const uint32_t qlen = n3 - sscore + 1u;
         RunState st; st.in_run = 1; st.run_start = 0; st.best = 0; st.best_start = 0;   // qtr starts at startscore (1055)
+        if (qlen > 1024u) {
+            // a line of thousands of scores: every lane sums up sixteen scores of each KiB, the sums are merged over the
+            // wave (kvq_long_line_run, kernels_bp.hip) -- fed 64 scores at a time it is a chain of thousands of steps
+            kvq_long_line_run(data + sscore, qlen - 1u, P.amin, lane, st.best, st.best_start);
+        } else
         for (uint32_t o4 = 0; o4 < qlen; o4 += 1024u) {
-            // (sixteen loads in flight: a score line of thousands of bytes is a chain of memory round trips otherwise;
-            // ordinary reads are done with the first few)
+            // (sixteen loads in flight; ordinary reads are done with the first few)
             uint8_t by[16]; bool ok[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -291,6 +326,10 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
             }
             read_off[g] = sread + st.best_start;                          // 1070
             read_len[g] = rl >= P.minreadlength ? rl : -1;
+            if (long_count && rl >= KVQ_LONG_READ && rl >= P.minreadlength) {
+                const unsigned int i = atomicAdd(long_count, 1u);
+                if (i < KVQ_LONG_CAP) { read_off[long_top - i] = sread + st.best_start; read_len[long_top - i] = rl; read_len[g] = -1; }
+            }
         }
     }
     }
@@ -328,8 +367,37 @@ __device__ __forceinline__ bool within_budget(const uint8_t *x, const uint8_t *y
     return e <= budget;
 }
 
-// one wave per read; lanes share out the alignments ("jobs") of the read
-// against one sequence: class A jobs, then class B, then class C.
+// The alignments ("jobs") of one read against one sequence, in emission order: class A (tail of the read over the head of
+// the sequence, 1116), class B (head of the read over the tail of the sequence, 1130), class C (one inside the other,
+// 1147 / 1163).  Job j compares `len` bases from read offset ri and sequence offset si.
+struct KvqJobs { int nA, nB, njobs, iA_hi, iB_hi; };
+__device__ __forceinline__ KvqJobs kvq_jobs_of(int rl, int seql, int mo)
+{
+    KvqJobs J; J.nA = 0; J.nB = 0; J.iA_hi = 0; J.iB_hi = 0;
+    if (rl > mo && seql > mo) {
+        J.iA_hi = rl - mo;                                     // A: i = iA_hi .. iA_lo (1116)
+        const int iA_lo = (rl - seql + 1) > 1 ? (rl - seql + 1) : 1;
+        J.nA = J.iA_hi - iA_lo + 1; if (J.nA < 0) J.nA = 0;
+        J.iB_hi = seql - mo;                                   // B: i = iB_hi .. iB_lo (1130)
+        const int iB_lo = (seql - rl) > 1 ? (seql - rl) : 1;
+        J.nB = J.iB_hi - iB_lo + 1; if (J.nB < 0) J.nB = 0;
+    }
+    J.njobs = J.nA + J.nB + (rl > seql ? rl - seql : seql - rl) + 1;   // 1147 / 1163
+    return J;
+}
+__device__ __forceinline__ void kvq_job(const KvqJobs &J, int j, int rl, int seql, int &ri, int &si, int &len, int &spos, uint32_t &key)
+{
+    if (j < J.nA) { const int i = J.iA_hi - j; ri = i; si = 0; len = rl - i; spos = -i; key = (0u << 30) | (uint32_t)j; }
+    else if (j < J.nA + J.nB) { const int i = J.iB_hi - (j - J.nA); ri = 0; si = i; len = seql - i; spos = i; key = (1u << 30) | (uint32_t)(j - J.nA); }
+    else {
+        const int i = j - J.nA - J.nB;
+        key = (2u << 30) | (uint32_t)i;
+        if (rl > seql) { ri = i; si = 0; len = seql; spos = -i; }
+        else           { ri = 0; si = i; len = rl;   spos = i; }
+    }
+}
+
+// one wave per read; lanes share out the jobs of the read against one sequence
 extern "C" __global__ void __launch_bounds__(256)
 kvq_match_all(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, uint32_t nrec_, KvqDevCount dc,
               const uint32_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
@@ -344,44 +412,110 @@ kvq_match_all(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, 
     const int64_t fpos = fpos_base + read_off[g];
     const int mo = P.minoverlap, me = P.maxerrors;
 
-    for (int q = (int)blockIdx.y; q < nlist; q += (int)gridDim.y) {      // (gridDim.y > 1: the sequences of a read shared out, for a few long reads)
+    for (int q = (int)blockIdx.y; q < nlist; q += (int)gridDim.y) {      // (gridDim.y > 1: the sequences of a read shared out)
         const int s = seq_list[q];
         const uint8_t *seq = P.tab + P.tab_off[s];
         const int seql = P.tab_off[s + 1] - P.tab_off[s];
-        // job ranges, in emission order
-        int nA = 0, nB = 0, iA_hi = 0, iB_hi = 0;
-        if (rl > mo && seql > mo) {
-            iA_hi = rl - mo;                                   // A: i = iA_hi .. iA_lo (1116)
-            const int iA_lo = (rl - seql + 1) > 1 ? (rl - seql + 1) : 1;
-            nA = iA_hi - iA_lo + 1; if (nA < 0) nA = 0;
-            iB_hi = seql - mo;                                 // B: i = iB_hi .. iB_lo (1130)
-            const int iB_lo = (seql - rl) > 1 ? (seql - rl) : 1;
-            nB = iB_hi - iB_lo + 1; if (nB < 0) nB = 0;
-        }
-        const int nC = (rl > seql ? rl - seql : seql - rl) + 1;   // 1147 / 1163
-        const int njobs = nA + nB + nC;
-        for (int j0 = 64 * (int)blockIdx.z; j0 < njobs; j0 += 64 * (int)gridDim.z) {      // (gridDim.z > 1: the alignments of one long read shared out as well)
+        const KvqJobs J = kvq_jobs_of(rl, seql, mo);
+        for (int j0 = 64 * (int)blockIdx.z; j0 < J.njobs; j0 += 64 * (int)gridDim.z) {
             const int j = j0 + lane;
-            bool hit = false; int spos = 0, len = 0; uint32_t key = 0;
-            if (j < njobs) {
-                if (j < nA) {                                  // tail of read over head of sequence
-                    const int i = iA_hi - j;
-                    len = rl - i; spos = -i; key = (0u << 30) | (uint32_t)j;
-                    hit = within_budget(read + i, seq, len, me);
-                } else if (j < nA + nB) {                      // head of read over tail of sequence
-                    const int i = iB_hi - (j - nA);
-                    len = seql - i; spos = i; key = (1u << 30) | (uint32_t)(j - nA);
-                    hit = within_budget(seq + i, read, len, me);
-                } else {
-                    const int i = j - nA - nB;
-                    key = (2u << 30) | (uint32_t)i;
-                    if (rl > seql) { len = seql; spos = -i; hit = within_budget(read + i, seq, len, me); }
-                    else           { len = rl;   spos = i;  hit = within_budget(seq + i, read, len, me); }
-                }
+            bool hit = false; int ri = 0, si = 0, spos = 0, len = 0; uint32_t key = 0;
+            if (j < J.njobs) {
+                kvq_job(J, j, rl, seql, ri, si, len, spos, key);
+                hit = within_budget(read + ri, seq + si, len, me);
             }
             kvq_emit(P, hit, fpos, s, spos, len, rl, key);
         }
     }
+    }
+}
+
+// The same for the few LONG reads that the redo of skipped tiles meets (kvq_trim_records puts them on a list of their own,
+// read_off / read_len [long_top], [long_top - 1], ...): a workgroup per read, sequence group (blockIdx.y) and share of the
+// alignments (blockIdx.z), the read's bases in LDS -- the thousands of alignments of such a read against every sequence
+// are a chain of memory round trips otherwise.  A read that does not fit the LDS buffer is compared out of global memory.
+#define KVQ_LONG_LDS 16384u
+__device__ __forceinline__ bool within_budget_lds(const uint32_t *R, uint32_t x, const uint8_t *y, int n, int budget)
+{
+    // x: byte offset of the read's bases in R (any alignment: two words and a funnel shift)
+    auto word = [&](uint32_t o) { const uint32_t w = o >> 2; return __builtin_amdgcn_alignbit(R[w + 1], R[w], (o & 3u) * 8u); };
+    int e = 0, j = 0;
+    for (; j + 8 <= n; j += 8) {
+        uint32_t b0, b1;
+        __builtin_memcpy(&b0, y + j, 4); __builtin_memcpy(&b1, y + j + 4, 4);
+        const uint32_t v0 = word(x + (uint32_t)j) ^ b0, v1 = word(x + (uint32_t)j + 4u) ^ b1;
+        e += __popc((((v0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v0) & 0x80808080u) + __popc((((v1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v1) & 0x80808080u);
+        if (e > budget) return false;
+    }
+    for (; j < n; j++) {
+        e += ((word(x + (uint32_t)j) & 0xFFu) != y[j]);
+        if (e > budget) return false;
+    }
+    return e <= budget;
+}
+
+#define KVQ_LONG_NZ 2u              // a read's alignments against one sequence are shared out over so many waves
+extern "C" __global__ void __launch_bounds__(256)
+kvq_match_long(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, KvqDevCount dc,
+               const uint32_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
+               const int32_t *__restrict__ seq_list, int32_t nlist, uint32_t long_top)
+{
+    // work units (read, group of four sequences -- a wave each --, share of the alignments), dealt out over the grid in
+    // turn: a launch of fixed size serves one long read as evenly as a thousand
+    __shared__ uint32_t R[KVQ_LONG_LDS / 4u + 2u];
+    const int lane = kvq_lane(), wave = (int)(threadIdx.x >> 6);
+    uint32_t nrec = kvq_dev_count(0u, dc);
+    if (nrec > KVQ_LONG_CAP) nrec = KVQ_LONG_CAP;
+    const uint32_t ngroups = ((uint32_t)nlist + 3u) / 4u, per_read = ngroups * KVQ_LONG_NZ;
+    const uint32_t units = nrec * per_read;                           // (<= 2048 x 16384 x 2)
+    const int mo = P.minoverlap, me = P.maxerrors;
+    for (uint32_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const uint32_t g = long_top - u / per_read, rem = u % per_read;
+        const int q = (int)(rem / KVQ_LONG_NZ) * 4 + wave, z = (int)(rem % KVQ_LONG_NZ);
+        const int rl = read_len[g];
+        const uint32_t ro = read_off[g];
+        // the wave's sequence: its number, its place in the table, its first eight bases (on their way while the read
+        // is being staged) -- nearly all alignments of a long read start at the head of the sequence, and one that has too
+        // many mismatches in those eight bases, nearly every one, never touches global memory
+        int s = 0, seql = 0; const uint8_t *seq = P.tab; uint32_t s0 = 0, s1 = 0;
+        if (q < nlist) {
+            s = seq_list[q];
+            const int off = P.tab_off[s]; seql = P.tab_off[s + 1] - off; seq = P.tab + off;
+            if (seql >= 8) { __builtin_memcpy(&s0, seq, 4); __builtin_memcpy(&s1, seq + 4, 4); }
+        }
+        const uint8_t *read = data + ro;
+        const int64_t fpos = fpos_base + ro;
+        // the read's bases, from the aligned word in front of them on (the text is 16-byte aligned, check_batch)
+        const uint32_t sh = ro & 3u;
+        const bool in_lds = rl >= 0 && (uint32_t)rl + sh <= KVQ_LONG_LDS;
+        __syncthreads();                                                // (the last unit's comparisons are over)
+        if (in_lds) {
+            const uint32_t words = ((uint32_t)rl + sh + 3u) / 4u;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(data + (ro - sh));
+            for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) R[w] = src[w];
+            if (threadIdx.x < 2u) R[words + threadIdx.x] = 0u;
+        }
+        __syncthreads();
+        if (rl < 0 || q >= nlist) continue;
+        const KvqJobs J = kvq_jobs_of(rl, seql, mo);
+        for (int j0 = 64 * z; j0 < J.njobs; j0 += 64 * (int)KVQ_LONG_NZ) {
+            const int j = j0 + lane;
+            bool hit = false; int ri = 0, si = 0, spos = 0, len = 0; uint32_t key = 0;
+            if (j < J.njobs) {
+                kvq_job(J, j, rl, seql, ri, si, len, spos, key);
+                if (!in_lds) hit = within_budget(read + ri, seq + si, len, me);
+                else {
+                    bool maybe = true;
+                    if (si == 0 && len >= 8) {
+                        const uint32_t x = sh + (uint32_t)ri, w = x >> 2, b = (x & 3u) * 8u;
+                        const uint32_t v0 = __builtin_amdgcn_alignbit(R[w + 1], R[w], b) ^ s0, v1 = __builtin_amdgcn_alignbit(R[w + 2], R[w + 1], b) ^ s1;
+                        maybe = __popc((((v0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v0) & 0x80808080u) + __popc((((v1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v1) & 0x80808080u) <= me;
+                    }
+                    hit = maybe && within_budget_lds(R, sh + (uint32_t)ri, seq + si, len, me);
+                }
+            }
+            kvq_emit(P, hit, fpos, s, spos, len, rl, key);
+        }
     }
 }
 

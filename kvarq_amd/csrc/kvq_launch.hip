@@ -62,7 +62,6 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     const uint32_t grid_seeded = (uint32_t)std::min<uint64_t>(nt, grid_cap);
     uint32_t *d_first = reinterpret_cast<uint32_t *>(s->pool.d + first_at);
     const BpArgs *d_args = reinterpret_cast<const BpArgs *>(s->pool.d + first_at + first_b);
-    const KvqParams *d_params = &d_args->P;
     uint32_t *d_tchunk = reinterpret_cast<uint32_t *>(s->pool.d + chunk_at);
     uint32_t *d_report = reinterpret_cast<uint32_t *>(s->pool.d + report_at);
     const size_t ctr_at = first_at + first_b + ((sizeof(BpArgs) + 127) & ~(size_t)127);

@@ -589,7 +589,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
             const uint32_t per_block = 4 * 16;       // KVQ_TRIM_RPW records per wave
             hipLaunchKernelGGL(kvq_trim_records, dim3((uint32_t)((R + per_block - 1) / per_block)), dim3(256), 0, s->stream, P, d_data,
                                fpos_base, (uint32_t)R, KvqDevCount{ nullptr, 0, 0, nullptr }, s->d_nl4.as<uint32_t>(), s->d_rec_start.as<uint32_t>(),
-                               s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), hist_done ? 0 : 1, 16u);
+                               s->d_read_off.as<uint32_t>(), s->d_read_len.as<int32_t>(), hist_done ? 0 : 1, 16u, (unsigned int *)nullptr, 0u);
             if (n_exh > 0) {
                 const bool main_here = !use_seeded;
                 if (main_here) { if ((rc = new_event_pair(s, s->ev_main))) return rc; KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream)); }
@@ -611,18 +611,25 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
         const KvqRedo Rd(s->d_redo.p);
         unsigned int *const failw = s->d_fail + batch_no;
         const KvqSkippedTile *tiles = reinterpret_cast<const KvqSkippedTile *>(s->pool.d + s->cur_skip_at);
-        const KvqDevCount ntile{ failw, 8, KVQ_SKIP_CAP, failw }, nrec{ Rd.count, 0, KVQ_REDO_CAP, failw };
-        hipLaunchKernelGGL(kvq_collect_skipped, dim3(16), dim3(256), 0, s->stream, d_data, tiles, 0u, ntile, Rd.nl4, Rd.rec_start, Rd.count, KVQ_REDO_CAP);
+        const KvqDevCount ntile{ failw, 8, KVQ_SKIP_CAP, failw }, nrec{ Rd.count, 0, KVQ_REDO_CAP - KVQ_LONG_CAP, failw }, nlong{ Rd.count + 1, 0, 0xFFFFFFFFu, failw };
+        hipLaunchKernelGGL(kvq_collect_skipped, dim3(16), dim3(256), 0, s->stream, d_data, tiles, 0u, ntile, Rd.nl4, Rd.rec_start, Rd.count, KVQ_REDO_CAP - KVQ_LONG_CAP);
         // (few records, some of them very long: a wave per record for the trim; the matcher shares a record's sequences and
         // alignments out over many waves)
-        hipLaunchKernelGGL(kvq_trim_records, dim3(32), dim3(256), 0, s->stream, P, d_data, fpos_base, 0u, nrec, Rd.nl4, Rd.rec_start, Rd.read_off, Rd.read_len, 1, 1u);
-        // (the matcher's grid: small as long as this scan object has never had a skipped tile -- an empty launch of sixteen
-        // thousand workgroups costs 50 us, one of 256 next to nothing -- wide once it has: a handful of records of thousands
-        // of bases against every sequence is only quick when it is spread out)
-        const dim3 mgrid = s->seen_skips ? dim3(8, (uint32_t)std::min<size_t>(s->t->seeded.size(), 128), 16) : dim3(4, (uint32_t)std::min<size_t>(s->t->seeded.size(), 16), 4);
-        if (!s->t->seeded.empty())
-            hipLaunchKernelGGL(kvq_match_all, mgrid, dim3(256), 0, s->stream, P, d_data, fpos_base, 0u, nrec,
+        hipLaunchKernelGGL(kvq_trim_records, dim3(32), dim3(256), 0, s->stream, P, d_data, fpos_base, 0u, nrec, Rd.nl4, Rd.rec_start, Rd.read_off, Rd.read_len, 1, 1u, Rd.count + 1, KVQ_REDO_CAP - 1u);
+        // The matcher, twice: the ordinary reads a wave each (the sequences of a read shared out over a few workgroups), the
+        // long ones -- a handful of reads of thousands of bases, which the trim has put on a list of their own -- spread out
+        // over sequences and alignments.  Grids of a fixed, modest size (an empty launch of sixteen thousand workgroups costs
+        // 50 us, one of a few hundred next to nothing; the kernels stride over what there is): small as long as this scan
+        // object has never had a skipped tile.
+        static const char *mg = getenv("KVQ_MGRID");           // (experiments: workgroups of the long reads' launch)
+        const uint32_t lgrid = mg && atoi(mg) > 0 ? (uint32_t)atoi(mg) : 1536u;
+        const dim3 ogrid = s->seen_skips ? dim3(128, (uint32_t)std::min<size_t>(s->t->seeded.size(), 4), 1) : dim3(16, (uint32_t)std::min<size_t>(s->t->seeded.size(), 4), 1);
+        if (!s->t->seeded.empty()) {
+            hipLaunchKernelGGL(kvq_match_all, ogrid, dim3(256), 0, s->stream, P, d_data, fpos_base, 0u, nrec,
                                Rd.read_off, Rd.read_len, s->t->d_seeded.as<int32_t>(), (int32_t)s->t->seeded.size());
+            hipLaunchKernelGGL(kvq_match_long, dim3(s->seen_skips ? lgrid : 256u), dim3(256), 0, s->stream, P, d_data, fpos_base, nlong,
+                               Rd.read_off, Rd.read_len, s->t->d_seeded.as<int32_t>(), (int32_t)s->t->seeded.size(), KVQ_REDO_CAP - 1u);
+        }
     }
     // hits of this batch = arena[range[batch_no], range[batch_no + 1]) (kvq_commit_batch closes the range)
     if (use_seeded)
@@ -889,7 +896,11 @@ static int finish_once(kvq_scan *s)
         for (auto &e : s->ev_all) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_all += ms; }
         for (auto &e : s->ev_main) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_main += ms; }
         s->finished = true;
-        if (g_timing) fprintf(stderr, "finish: enqueue + wait %.3f  rest %.3f ms (%u hits)\n", t1 - t0, now_ms() - t1, n_hits);
+        if (g_timing) {
+            unsigned int rc2[2] = { 0, 0 };
+            if (s->d_redo.p) (void)hipMemcpy(rc2, s->d_redo.p, 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "finish: enqueue + wait %.3f  rest %.3f ms (%u hits; the last launch's skipped tiles left %u records, %u of them long)\n", t1 - t0, now_ms() - t1, n_hits, rc2[0], rc2[1]);
+        }
         return KVQ_OK;
     }
     kvq_set_error(KVQ_ERR_RUNTIME, "a redone batch failed validation again");

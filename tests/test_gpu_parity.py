@@ -641,6 +641,64 @@ def test_one_long_record_costs_its_tile_not_the_batch():
     s.close(); t.close()
 
 
+def test_long_records_with_ragged_quality_go_through_the_redo_exactly():
+    """a dozen records of 1.1 .. 9 kB that outgrow their tiles' look-ahead, their score lines full of dips, ties between
+    equally long good runs and runs that cross the 16-byte, 1 KiB and 4 KiB seams of the wave-parallel trim: hits, read
+    lengths and counters equal the oracle's (the redo of skipped tiles: kvq_collect_skipped, kvq_trim_records'
+    long-line path, the matcher's launch for long reads)"""
+    import random
+    rng = random.Random(20261004)
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g))
+    n, L = 120000, 150
+    rb = synth.record_bytes(L)
+    plain = synth.reads(g, 0, n, L)
+    co_plain = scan.chunk_offsets(plain)
+    pieces, at = [], 0
+    lens = [1100, 2047, 2048, 2049, 4095, 4096, 4097, 5000, 6000, 8191, 9000, 1025]
+    tabs = synth.table(g)
+    for i, ln in enumerate(lens):
+        c = 1 + i * ((len(co_plain) - 2) // len(lens))
+        cut = int(co_plain[c]) + 108 * rb                          # (inside the chunk's first tile, the record's end beyond its look-ahead)
+        st = rng.randrange(0, len(g) - ln - 1)
+        bases = bytes(g[st:st + ln])
+        q = bytearray(b'I' * ln)
+        kind = i % 4
+        if kind == 0:                                              # dips everywhere
+            for _ in range(ln // 40): q[rng.randrange(ln)] = ord('#')
+        elif kind == 1:                                            # two equally long best runs: the first one wins
+            run = ln // 3
+            q[:] = b'#' * ln
+            a = rng.randrange(1, ln - 2 * run - 2); b = a + run + 1 + rng.randrange(0, ln - a - 2 * run - 1)
+            q[a:a + run] = b'I' * run; q[b:b + run] = b'I' * run
+        elif kind == 2:                                            # the best run ends with the line (closed by its newline)
+            for _ in range(ln // 100): q[rng.randrange(ln // 2)] = ord('#')
+        else:                                                      # short runs, the longest somewhere across a 1 KiB seam
+            q[:] = bytes(rng.choice(b'#I') for _ in range(ln))
+            a = 1024 * (1 + rng.randrange(max(1, ln // 1024 - 1))) - 37
+            q[a:a + 90] = b'I' * 90; q[a - 1:a] = b'#'; q[a + 90:a + 91] = b'#'
+        pieces.append(plain[at:cut].tobytes()); at = cut
+        pieces.append(b'@long%d 1:N:0\n' % i + bases + b'\n+\n' + bytes(q) + b'\n')
+    pieces.append(plain[at:].tobytes())
+    text = np.frombuffer(b''.join(pieces), dtype=np.uint8)
+    cfg = dict(cases.PRODUCT)
+    o = O.scan_memory(text, seqs, fold=True, **dict(cfg, nthreads=16))
+    t = scan.Table(seqs, **cfg)
+    s = scan.Scanner(t)
+    d = scan.DeviceBuffer(text.nbytes); d.upload(text)
+    co = scan.chunk_offsets(text)
+    for rep in range(2):                                           # (the second time the launches for a scan that has seen skipped tiles)
+        s.reset()
+        s.scan_device(d.ptr, text.nbytes, co)
+        r = s.finish()
+        assert r['path'] == REDO_PATH, r['path']
+        assert tuple(r['hits']) == tuple(o['hits']) and r['hitseqs'] == o['hitseqs']
+        assert r['coverage'].tolist() == o['coverage'] and r['mutations'].tolist() == o['mutations']
+        assert r['stats']['records_parsed'] == n + len(lens) and r['stats']['readlengths'] == o['stats']['readlengths']
+        assert r['stats']['nseqhits'] == o['stats']['nseqhits'] and r['stats']['nseqbasehits'] == o['stats']['nseqbasehits']
+    d.free(); s.close(); t.close()
+
+
 def test_speculation_failure_falls_back_to_the_exact_split():
     """a FastQ whose base lines may start with '@' or '+' defeats the text heuristic;
     the validation pass must notice and the rescan must give the reference's answer"""

@@ -68,7 +68,7 @@ def main():
         t1 = time.perf_counter()
         s.scan_device(d.ptr, text.nbytes, co)
         r = s.finish(hits=False, stats=(it == 5))
-        dt = time.perf_counter() - t1
+        if it < 5: dt = time.perf_counter() - t1                  # (the timed step: without the statistics as Python objects, which the last round fetches)
     # the same with three jobs in flight, as bench.py runs them (the next scan is enqueued before the last one's results
     # are waited for: a tile's records that go round again through the host then cost GPU time, not idle time)
     ring = [s, scan.Scanner(t), scan.Scanner(t)]
