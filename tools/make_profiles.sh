@@ -5,6 +5,7 @@
 # PMC passes are separate runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes.
 set -u
 TAG=${1:-round3}
+PART=${2:-ab}            # a: traces, counters and the bench line; b: the other measurements (two gpurun calls of <= 20 min each)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -13,6 +14,7 @@ B="python3 $R/bench.py --no-end-to-end"
 BP="$B --preheat 0"          # counter passes: every launch is counted, no need to heat the clocks
 step() { echo "== $1" >> $O/progress.txt; }
 
+if [[ $PART == *a* ]]; then
 step stats;  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 5 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
 step stats1; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- $B --pipeline 1 --steps 5 --warmup 1 --no-cpu-baseline > $O/stats1.log 2>&1
 step fetch;  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
@@ -34,22 +36,28 @@ for d in 0 1 2 32; do
   echo "== KVQ_DBG=$d (0: whole kernel, 1: no verify, 2: no filter and verify, 32: front end only); 5 M reads per launch" >> $O/pmc_phases.txt
   python3 tools/pmc_sum.py $O/ph$d kvq_scan_ >> $O/pmc_phases.txt
 done
+fi
+if [[ $PART == *b* ]]; then
 step configs; bash tools/other_configs.sh $TAG > /dev/null 2>&1
 step filerate; timeout -k 10 200 python3 tools/file_rate.py > $O/file_rate.txt 2>&1
 step filepath; KVQ_TIMING=1 timeout -k 10 200 python3 tools/r3_file.py 10000000 4 8 16 2>&1 | grep 'stream_batches\|plain file\|findseqs:' > $O/file_path.txt
-step long; ( timeout -k 10 200 python3 tools/realistic_bench.py 3000000; timeout -k 10 200 python3 tools/realistic_bench.py 3000000 100000 ) > $O/long_reads.txt 2>&1
+step long; ( timeout -k 10 200 python3 tools/realistic_bench.py 3000000; timeout -k 10 200 python3 tools/realistic_bench.py 3000000 100000; LONG_EVERY=100000 bash tools/r3_long_trace.sh ) 2>&1 | grep -v amdgpu.ids > $O/long_reads.txt
+step hostceiling; timeout -k 10 200 python3 tools/r3_h2d.py 64 4 8 16 2>&1 | grep -v amdgpu.ids > $O/host_ceiling.txt
 step probes; bash tools/r3_probe_ablation.sh > $O/probe_ablation.txt 2>&1
 step sizes; bash tools/r3_sizes.sh > $O/kernel_time_by_size.txt 2>&1
-step occ; bash tools/r3_occ.sh v2 > $O/time_by_occupancy.txt 2>&1
+step occ; bash tools/r3_occ.sh > $O/time_by_occupancy.txt 2>&1
 step clock; bash tools/clock_pmc.sh $TAG/clk > $O/clock.txt 2>&1
 step ubench
 ( cd tools/ubench && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o valu_rate valu_rate.hip 2>/dev/null && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o issue_rate issue_rate.hip 2>/dev/null
   timeout -k 10 120 ./valu_rate > $O/valu_rate.txt 2>&1 && timeout -k 10 120 ./issue_rate > $O/issue_rate.txt 2>&1 )
+fi
+if [[ $PART == *a* ]]; then
 # the bench line last: it quotes the traffic file made above (same sources)
 step bench;  cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json; timeout -k 10 500 python3 bench.py > $O/bench_n1.json 2> $O/bench.err
 timeout -k 10 400 python3 bench.py --pipeline 1 --no-cpu-baseline --no-end-to-end > $O/bench_n1_pipeline1.json 2>> $O/bench.err
+fi
 step done
-for f in bench_n1.json bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt file_path.txt long_reads.txt probe_ablation.txt kernel_time_by_size.txt time_by_occupancy.txt clock.txt valu_rate.txt issue_rate.txt; do
+for f in bench_n1.json bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt file_path.txt long_reads.txt host_ceiling.txt probe_ablation.txt kernel_time_by_size.txt time_by_occupancy.txt clock.txt valu_rate.txt issue_rate.txt; do
   echo "cp gpurun_out/$TAG/$f profiles/${TAG}_$f"
 done
-cat $O/bench_n1.json
+[[ $PART == *a* ]] && cat $O/bench_n1.json
