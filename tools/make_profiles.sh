@@ -38,6 +38,7 @@ for d in 0 1 2 32; do
 done
 fi
 if [[ $PART == *b* ]]; then
+cd $R
 step configs; bash tools/other_configs.sh $TAG > /dev/null 2>&1
 step filerate; timeout -k 10 200 python3 tools/file_rate.py > $O/file_rate.txt 2>&1
 step filepath; KVQ_TIMING=1 timeout -k 10 200 python3 tools/r3_file.py 10000000 4 8 16 2>&1 | grep 'stream_batches\|plain file\|findseqs:' > $O/file_path.txt
@@ -52,6 +53,7 @@ step ubench
   timeout -k 10 120 ./valu_rate > $O/valu_rate.txt 2>&1 && timeout -k 10 120 ./issue_rate > $O/issue_rate.txt 2>&1 )
 fi
 if [[ $PART == *a* ]]; then
+cd $R
 # the bench line last: it quotes the traffic file made above (same sources)
 step bench;  cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json; timeout -k 10 500 python3 bench.py > $O/bench_n1.json 2> $O/bench.err
 timeout -k 10 400 python3 bench.py --pipeline 1 --no-cpu-baseline --no-end-to-end > $O/bench_n1_pipeline1.json 2>> $O/bench.err
