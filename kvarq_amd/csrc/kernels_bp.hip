@@ -214,7 +214,9 @@ struct BpArgs {
     SeedTables X;
     const uint8_t *data; int64_t fpos_base;
     const uint4 *tiles; uint32_t *tile_report; unsigned int *tile_ctr;
-    uint32_t ntiles, tile_bytes, dbg, pad_;
+    void *redo;                       // KvqRedo: where a read that floods its wave's queues is put for the exhaustive matcher
+    unsigned int *fail;               // the batch's fail word (bit 1: such reads exist)
+    uint32_t ntiles, tile_bytes, dbg, pad_, redo_cap, pad2_;
 };
 // Tiles are handed out by counters.  One counter for the whole launch is a ceiling by itself: a word in
 // memory takes about 88 atomic adds per microsecond (MI355X_MICROARCH.md, "dequeue"), i.e. 3.5 TB/s of
@@ -835,17 +837,38 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                         if (base + j < BP_Q2W) q2[base + j] = (qi << 22) | (en0 + j);
                     q2n += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                 }
-                const bool over = over1 || q2n > BP_Q2W;
+                const bool over = over1;                                  // (work items never run over: they are dealt with a queue-full at a time, below)
                 if (over && step > 1u) { step >>= 1; continue; }
-                if (over && lane == 0) S.fallback = 1u;                   // one read floods the queues: the batch goes to the exhaustive kernels
+                if (over) {
+                    // ONE read has more candidates than the queue holds (step == 1): it alone goes to the exhaustive matcher behind the scan (the redo's
+                    // list: trimmed and counted here, KVQ_REDO_TRIMMED), its tile carries on; a full list fails the batch
+                    if (mine && gl == 0) {
+                        const BpArgsPtr A = bp_args(A_);
+                        const KvqRedo Rd(A->redo);
+                        const uint32_t boff = g0 - ST_PRE + roff;
+                        bool put = false;
+                        if (A->redo) {
+                            if (rl >= KVQ_LONG_READ) {
+                                const unsigned int i = atomicAdd(Rd.count + 1, 1u);
+                                if (i < KVQ_LONG_CAP) { Rd.read_off[KVQ_REDO_CAP - 1u - i] = boff; Rd.read_len[KVQ_REDO_CAP - 1u - i] = rl; put = true; }
+                            }
+                            if (!put) {
+                                const unsigned int i = atomicAdd(Rd.count, 1u);
+                                if (i < A->redo_cap) { Rd.rec_start[i] = KVQ_REDO_TRIMMED; Rd.read_off[i] = boff; Rd.read_len[i] = rl; }
+                                put = true;                                  // (beyond the cap: kvq_dev_count fails the batch)
+                            }
+                        }
+                        if (!put) S.fallback = 1u;
+                        else atomicOr(A->fail, 2u);                      // (reported as records that went through the exhaustive kernels; the next launches of this scan object use the wide grids)
+                    }
+                }
 
         KVQ_MARK("P4b");
                 // ---- P4b: one work item per lane ----
-                {
-                    const uint32_t q2n_ok = over ? 0u : q2n;
-                    for (uint32_t i0 = 0; i0 < q2n_ok; i0 += 64u) {
+                auto verify_queue = [&](uint32_t n_items) {
+                    for (uint32_t i0 = 0; i0 < n_items; i0 += 64u) {
                         const uint32_t ii = i0 + lane;
-                        const bool active = ii < q2n_ok;
+                        const bool active = ii < n_items;
                         uint32_t rec = 0, kind = 0; int p = 0; uint64_t en = 0;
                         if (active) {
                             const uint32_t it = q2[ii];
@@ -854,6 +877,32 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                             en = (kind ? ent_all : ent_anc)[it & 0x3FFFFFu];
                         }
                         verify_item_bp(H, S, text, active, rec, p, kind, en, tile_fpos, SS);
+                    }
+                };
+                verify_queue(q2n < BP_Q2W ? q2n : BP_Q2W);
+                // (dense tables: a read that matches dozens of sequences has more work items than the queue holds.  The items
+                // are numbered in candidate order, the queue has taken the first BP_Q2W; for every further queue-full [w0, w0 +
+                // BP_Q2W) the candidates, a hundred at most, are simply walked again)
+                if (__builtin_expect(q2n > BP_Q2W, 0)) {
+                    const uint32_t total = q2n;
+                    for (uint32_t w0 = BP_Q2W; w0 < total; w0 += BP_Q2W) {
+                        uint32_t run = 0;
+                        for (uint32_t q0 = 0; q0 < qn_ok; q0 += 64u) {
+                            const uint32_t qi = q0 + lane;
+                            uint32_t en0 = 0, ne = 0;
+                            if (qi < qn_ok) {
+                                const uint32_t cd = q1[qi];
+                                const uint32_t code = cdp_code8((S.rinfo[cd & 511u] & 0xFFFFu) + ((cd >> 9) & 0xFFFFu));
+                                const GlbWords st = (cd >> BP_Q1_KIND) ? start_all : start_anc;
+                                en0 = st[code]; ne = st[code + 1u] - en0;
+                            }
+                            const uint32_t inc = kvq_wave_incl_scan(ne);
+                            const uint32_t base = run + inc - ne - w0;                          // (unsigned: items in front of w0 wrap beyond the queue)
+                            for (uint32_t j = 0; j < ne; j++)
+                                if (base + j < BP_Q2W) q2[base + j] = (qi << 22) | (en0 + j);
+                            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                        }
+                        verify_queue(total - w0 < BP_Q2W ? total - w0 : BP_Q2W);
                     }
                 }
                 KVQ_SETPRIO(2);

@@ -249,8 +249,6 @@ __device__ __forceinline__ void run_feed(RunState &st, uint64_t good, int nbits,
 // the longest run of scores >= amin among line[0 .. Q) (the byte behind it closes the last run), the first of equally long
 // ones, by all 64 lanes of a wave; the answer in every lane (kernels_bp.hip)
 __device__ void kvq_long_line_run(const uint8_t *line, uint32_t Q, int amin, int lane, int &best, uint32_t &best_start);
-#define KVQ_LONG_READ 1024  // (redo of skipped tiles) reads from here on are matched by a launch of their own
-#define KVQ_LONG_CAP 2048u  // ... at most so many of them (the rest stays with the ordinary ones)
 
 // one wave per record, KVQ_TRIM_RPW consecutive records per wave.
 // read_off[g] = batch offset of the first base of the trimmed read,
@@ -279,9 +277,12 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
     const int lane = kvq_lane();
     for (uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6); (uint64_t)wave * rpw < nrec; wave += gridDim.x * 4u) {
     const uint32_t g_begin = wave * rpw;
-    if (lane == 0) atomicAdd(&nproc, nrec - g_begin < rpw ? nrec - g_begin : rpw);
     for (uint32_t g = g_begin; g < g_begin + rpw && g < nrec; g++) {
         const uint32_t rstart = rec_start[g];
+        // (the redo's list also holds reads that the scan kernel has trimmed itself and only could not match -- one read
+        // flooding its wave's queues: marked by this record start, read_off / read_len already in place, counted there)
+        if (rstart == KVQ_REDO_TRIMMED) continue;
+        if (lane == 0) atomicAdd(&nproc, 1u);
         const uint32_t n0 = nl4[4 * (size_t)g], n1 = nl4[4 * (size_t)g + 1], n2 = nl4[4 * (size_t)g + 2], n3 = nl4[4 * (size_t)g + 3];
         const uint32_t sread = n0 + 1u, plus = n1 + 1u, sscore = n2 + 1u;
         if (lane == 0) {

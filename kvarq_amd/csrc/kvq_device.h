@@ -123,3 +123,11 @@ __device__ __forceinline__ void kvq_emit(const KvqParams &P, bool hit, int64_t f
         }
     }
 }
+
+// the redo of what the fused scan leaves (kvq_runtime.hip: run_batch): reads of KVQ_LONG_READ bases or more are matched by a
+// launch of their own, at most KVQ_LONG_CAP of them; a list entry whose record start is KVQ_REDO_TRIMMED has been trimmed
+// (and counted) by the scan kernel already
+#define KVQ_LONG_READ 1024
+#define KVQ_LONG_CAP 2048u
+#define KVQ_REDO_TRIMMED 0xFFFFFFFFu
+

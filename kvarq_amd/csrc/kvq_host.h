@@ -76,7 +76,7 @@ struct kvq_comm;
 struct KvqRedo {                      // where the pieces lie inside kvq_scan::d_redo
     unsigned int *count; uint32_t *nl4, *rec_start, *read_off; int32_t *read_len;
     static size_t bytes() { return 256 + (size_t)KVQ_REDO_CAP * (16 + 4 + 4 + 4); }
-    explicit KvqRedo(void *p) { char *c = (char *)p; count = (unsigned int *)c; nl4 = (uint32_t *)(c + 256); rec_start = nl4 + 4 * (size_t)KVQ_REDO_CAP; read_off = rec_start + KVQ_REDO_CAP; read_len = (int32_t *)(read_off + KVQ_REDO_CAP); }
+    __host__ __device__ explicit KvqRedo(void *p) { char *c = (char *)p; count = (unsigned int *)c; nl4 = (uint32_t *)(c + 256); rec_start = nl4 + 4 * (size_t)KVQ_REDO_CAP; read_off = rec_start + KVQ_REDO_CAP; read_len = (int32_t *)(read_off + KVQ_REDO_CAP); }
 };
 int kvq_live_scans();                 // scan objects alive in this process
 // the persistent scan kernels of a process run one behind the other (two at once only get in each other's way): a launch waits for

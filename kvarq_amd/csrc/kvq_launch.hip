@@ -74,6 +74,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         a.tiles = reinterpret_cast<const uint4 *>(d_tchunk); a.tile_report = d_report; a.tile_ctr = d_tile_ctr;
         static const uint32_t stagger = (uint32_t)(getenv("KVQ_STAGGER") ? atoi(getenv("KVQ_STAGGER")) : 0);
         a.ntiles = (uint32_t)nt; a.tile_bytes = TILE; a.dbg = dbg; a.pad_ = stagger;
+        a.redo = s->d_redo.p; a.redo_cap = KVQ_REDO_CAP - KVQ_LONG_CAP; a.fail = s->cur_fail;
         memcpy(s->pool.h + first_at + first_b, &a, sizeof(a));
     }
     {

@@ -699,6 +699,84 @@ def test_long_records_with_ragged_quality_go_through_the_redo_exactly():
     d.free(); s.close(); t.close()
 
 
+def test_a_read_that_floods_its_waves_queues_is_matched_on_its_own():
+    """300 sequences that share a repeat: a read made of that repeat finds thousands of index entries, more than a wave's
+    queues hold even when it is the wave's only read.  Such a read goes to the exhaustive matcher on its own (the redo's
+    list, filled by the scan kernel), its tile and its batch carry on: same hits as the oracle, no rescan of the batch"""
+    import random
+    rng = random.Random(7)
+    unit = 'ACGTTGCA'
+    seqs = [unit * 5 + ''.join(rng.choice('ACGT') for _ in range(20)) for _ in range(300)]
+    g = synth.genome()
+    n, L = 20000, 150
+    rb = synth.record_bytes(L)
+    plain = synth.reads(g, 0, n, L)
+    flood = [(unit * 19)[:150], (unit * 19)[3:150], (unit * 200)[:1500], (unit * 19)[:150]]      # (one of them long: the long reads' launch)
+    pieces, at = [], 0
+    for i, b in enumerate(flood):
+        cut = (1 + i * 4500) * rb
+        pieces.append(plain[at:cut].tobytes()); at = cut
+        pieces.append(('@flood%d\n%s\n+\n%s\n' % (i, b, 'I' * len(b))).encode())
+    pieces.append(plain[at:].tobytes())
+    text = np.frombuffer(b''.join(pieces), dtype=np.uint8)
+    cfg = dict(cases.PRODUCT)
+    o = O.scan_memory(text, seqs, fold=True, **dict(cfg, nthreads=16))
+    assert len(o['hits']) > 1000
+    t = scan.Table(seqs, **cfg)
+    s = scan.Scanner(t)
+    d = scan.DeviceBuffer(text.nbytes); d.upload(text)
+    co = scan.chunk_offsets(text)
+    for rep in range(2):
+        s.reset()
+        s.scan_device(d.ptr, text.nbytes, co)
+        r = s.finish()
+        assert r['path'] == REDO_PATH, r['path']                   # (records behind the scan, not the batch again)
+        assert tuple(r['hits']) == tuple(o['hits']) and r['hitseqs'] == o['hitseqs']
+        assert r['coverage'].tolist() == o['coverage'] and r['mutations'].tolist() == o['mutations']
+        assert r['stats']['records_parsed'] == n + len(flood) and r['stats']['readlengths'] == o['stats']['readlengths']
+        assert r['stats']['nseqhits'] == o['stats']['nseqhits'] and r['stats']['nseqbasehits'] == o['stats']['nseqbasehits']
+    d.free(); s.close(); t.close()
+
+
+def test_reads_with_more_work_items_than_a_queue_holds_are_dealt_with_in_turns():
+    """a dense table -- 64 variants of each of four templates -- makes every read off a template meet thousands of
+    (candidate, index entry) pairs, many times what a wave's queue holds: the queue is filled and emptied in turns
+    (no redo, no rescan) and the hits equal the oracle's"""
+    import random
+    rng = random.Random(11)
+    g = synth.genome()
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    seqs, spots = [], [3000, 9000, 15000, 21000]
+    for a in spots:
+        base = bytes(g[a:a + 120])
+        for v in range(64):
+            b = bytearray(base)
+            b[60 + (v % 50)] = ord('ACGT'[(('ACGT'.index(chr(b[60 + (v % 50)]))) + 1 + v // 50) % 4])      # one changed base per variant
+            seqs.append(bytes(b[v % 7: 100 + v % 13]).decode())
+    n, L = 6000, 150
+    rb = synth.record_bytes(L)
+    plain = synth.reads(g, 0, n, L).tobytes()
+    recs = []
+    for i in range(400):                                             # reads off the templates, both strands, a few errors
+        a = rng.choice(spots) + rng.randrange(-60, 40)
+        b = bytearray(g[a:a + L])
+        for _ in range(rng.randrange(0, 3)): b[rng.randrange(L)] = ord(rng.choice('ACGT'))
+        if i & 1: b = bytearray(comp[c] for c in reversed(b))
+        recs.append(b'@dense%d\n' % i + bytes(b) + b'\n+\n' + b'I' * L + b'\n')
+    text = np.frombuffer(plain[:3000 * rb] + b''.join(recs) + plain[3000 * rb:], dtype=np.uint8)
+    cfg = dict(cases.PRODUCT)
+    o = O.scan_memory(text, seqs, fold=True, **dict(cfg, nthreads=16))
+    assert len(o['hits']) > 10000
+    t = scan.Table(seqs, **cfg)
+    s = scan.Scanner(t)
+    r = s.scan_host(text, scan.chunk_offsets(text)) or s.finish()
+    assert r['path'] == dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False), r['path']
+    assert tuple(r['hits']) == tuple(o['hits']) and r['hitseqs'] == o['hitseqs']
+    assert r['coverage'].tolist() == o['coverage'] and r['mutations'].tolist() == o['mutations']
+    assert r['stats']['nseqhits'] == o['stats']['nseqhits'] and r['stats']['nseqbasehits'] == o['stats']['nseqbasehits']
+    s.close(); t.close()
+
+
 def test_speculation_failure_falls_back_to_the_exact_split():
     """a FastQ whose base lines may start with '@' or '+' defeats the text heuristic;
     the validation pass must notice and the rescan must give the reference's answer"""
