@@ -23,6 +23,9 @@
 #include "kvq_host.h"
 
 // a comment line in the ISA text (tools/isa_marks.py counts the instructions between two of them)
+#ifndef KVQ_TEXT_AUX
+#define KVQ_TEXT_AUX 0          // cache policy of the tile's text loads (experiments: 1 sc0, 2 nt, 16 sc1)
+#endif
 #define KVQ_MARK(name) asm volatile("; KVQMARK " name)
 #define BP_WIN (ST_BUF + ST_BLK)   // bytes of text a tile's planes cover: 512 blocks of 80
 #define BP_Q1_KIND 25               // bit of a candidate word that says "fixed block, all-positions index"
@@ -415,7 +418,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(data + g0), 0, (int)(((load_hi + 15u) & ~15u) - g0), 0x00020000);
 #pragma unroll
             for (int r = 0; r < (int)ST_ROUNDS; r++) {
-                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(r ? vo + 1024u * r : vo0), 0, 0);
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(r ? vo + 1024u * r : vo0), 0, KVQ_TEXT_AUX);
                 pre[r] = make_uint4(v.x, v.y, v.z, v.w);
             }
         }
