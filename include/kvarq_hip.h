@@ -175,6 +175,8 @@ int64_t        kvq_scan_total(const kvq_scan *s);             /* fastq_size_esti
  * the dominant (read-scanning) kernel alone plus its launch count */
 double  kvq_scan_kernel_ms(const kvq_scan *s);
 double  kvq_scan_main_kernel_ms(const kvq_scan *s);
+/* (measurement) ms between the end of a's last main kernel and the start of b's first one; both finished, not reset since */
+double  kvq_scan_gap_ms(const kvq_scan *a, const kvq_scan *b);
 int64_t kvq_scan_main_kernel_launches(const kvq_scan *s);
 /* forget accumulated hits/counters/timers but keep buffers (bench steps) */
 int32_t kvq_scan_reset(kvq_scan *s);

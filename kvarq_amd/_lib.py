@@ -67,6 +67,7 @@ PROTOTYPES = {
     'kvq_scan_total': (i64, [vp]),
     'kvq_scan_kernel_ms': (C.c_double, [vp]),
     'kvq_scan_main_kernel_ms': (C.c_double, [vp]),
+    'kvq_scan_gap_ms': (C.c_double, [vp, vp]),
     'kvq_scan_main_kernel_launches': (i64, [vp]),
     'kvq_scan_reset': (i32, [vp]),
     'kvq_scan_path': (i32, [vp]),

@@ -35,11 +35,15 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     // workgroups per launch: what the CUs hold at once (four per CU)
     static const uint32_t grid_env = (uint32_t)(getenv("KVQ_GRID") ? atoi(getenv("KVQ_GRID")) : 0);
     // (a process that keeps several scan objects is taken to overlap their work -- the next job's scan with the
-    // last one's fold, ordering and copy: one CU in eight then keeps a workgroup slot free, so that those small
-    // kernels run beside the persistent workgroups of the scan instead of behind them; tools: bench.py --pipeline)
+    // last one's fold, ordering and copy: one CU in FOUR then keeps a workgroup slot free, so that those small
+    // kernels run beside the persistent workgroups of the scan instead of behind them.  Round 2 left one in eight: the
+    // kernels that stand in FRONT of the next scan (reset, table upload, kvq_expand_tiles) then queue for the same 32 slots
+    // behind the last step's ordering kernels and the next scan starts 140 us late (tools/r3_gap.py: 137 -> 20 us idle
+    // between scans; tools/r3_grid_sweep.sh: 992 workgroups 1.26 ms per step, 976 1.18, 960 1.18, 944 1.20, 928 1.20 --
+    // the scan kernel itself pays 1.5 % for the 64 slots))
     const uint32_t cus = s->cus ? s->cus : (s->cus = kvq_device_cu_count());      // (of the device this scan object lives on: a process may use several)
     const uint32_t per_cu = 4u;
-    const uint32_t grid_full = cus * per_cu, grid_shared = grid_full - cus / 8u;
+    const uint32_t grid_full = cus * per_cu, grid_shared = grid_full - cus / 4u;
     const uint32_t grid_cap = grid_env ? grid_env : (kvq_live_scans() > 1) ? grid_shared : grid_full;
     if (s->pool.used + ((size_t)nchunks + 1) * 4 + (size_t)nt * 24 + 24576 + KVQ_SKIP_CAP * sizeof(KvqSkippedTile) > s->pool.cap) {       // run_batch made the room
         kvq_set_error(KVQ_ERR_RUNTIME, "batch tables outgrew their reservation"); return KVQ_ERR_RUNTIME;

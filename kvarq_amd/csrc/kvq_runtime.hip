@@ -895,6 +895,7 @@ static int finish_once(kvq_scan *s)
         s->ms_all = s->ms_main = 0;
         for (auto &e : s->ev_all) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_all += ms; }
         for (auto &e : s->ev_main) { float ms = 0; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s->ms_main += ms; }
+        (void)hipGetLastError();                 // (a pair that was never recorded is not an error of the scan)
         s->finished = true;
         if (g_timing) {
             unsigned int rc2[2] = { 0, 0 };
@@ -993,6 +994,14 @@ extern "C" int64_t kvq_scan_parsed(const kvq_scan *s) { return s->parsed; }
 extern "C" int64_t kvq_scan_total(const kvq_scan *s) { return s->total; }
 extern "C" double kvq_scan_kernel_ms(const kvq_scan *s) { return s->ms_all; }
 extern "C" double kvq_scan_main_kernel_ms(const kvq_scan *s) { return s->ms_main; }
+// (measurement) ms from the end of a's last main kernel to the start of b's first one (both finished, neither reset since); < 0: unknown
+extern "C" double kvq_scan_gap_ms(const kvq_scan *a, const kvq_scan *b)
+{
+    if (!a || !b || a->ev_main.empty() || b->ev_main.empty()) return -1.0;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a->ev_main.back().second, b->ev_main.front().first) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
+    return (double)ms;
+}
 extern "C" int64_t kvq_scan_main_kernel_launches(const kvq_scan *s) { return s->main_launches; }
 
 // ---------------------------------------------------------------------------
