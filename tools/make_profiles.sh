@@ -43,6 +43,10 @@ step configs; bash tools/other_configs.sh $TAG > /dev/null 2>&1
 step filerate; timeout -k 10 200 python3 tools/file_rate.py > $O/file_rate.txt 2>&1
 step filepath; KVQ_TIMING=1 timeout -k 10 200 python3 tools/r3_file.py 10000000 4 8 16 2>&1 | grep 'stream_batches\|plain file\|findseqs:' > $O/file_path.txt
 step long; ( timeout -k 10 200 python3 tools/realistic_bench.py 3000000; timeout -k 10 200 python3 tools/realistic_bench.py 3000000 100000; LONG_EVERY=100000 bash tools/r3_long_trace.sh ) 2>&1 | grep -v amdgpu.ids > $O/long_reads.txt
+step gaps; ( timeout -k 10 200 python3 tools/r3_gap.py 10000000 40 3; timeout -k 10 200 python3 tools/r3_gap2.py; KVQ_GRID=992 timeout -k 10 200 python3 tools/r3_gap.py 10000000 40 3 | sed 's/^/KVQ_GRID=992 (round 2: 32 free slots)  /' ) 2>&1 | grep -v amdgpu.ids > $O/scan_gaps.txt
+step gridsweep; bash tools/r3_grid_sweep.sh "1024 992 976 960 944" > $O/grid_sweep.txt 2>&1
+step dense; ( for k in 8 16 32; do timeout -k 10 120 python3 tools/r3_dense.py $k 1000000 | tail -1; done ) > $O/dense_tables.txt 2>&1
+step h2dflags; timeout -k 10 200 python3 tools/r3_h2d_flags.py 64 8 2>&1 | grep -v amdgpu.ids > $O/host_ceiling_flags.txt
 step hostceiling; timeout -k 10 200 python3 tools/r3_h2d.py 64 4 8 16 2>&1 | grep -v amdgpu.ids > $O/host_ceiling.txt
 step probes; bash tools/r3_probe_ablation.sh > $O/probe_ablation.txt 2>&1
 step sizes; bash tools/r3_sizes.sh > $O/kernel_time_by_size.txt 2>&1
@@ -59,7 +63,7 @@ step bench;  cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json; timeout
 timeout -k 10 400 python3 bench.py --pipeline 1 --no-cpu-baseline --no-end-to-end > $O/bench_n1_pipeline1.json 2>> $O/bench.err
 fi
 step done
-for f in bench_n1.json bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt file_path.txt long_reads.txt host_ceiling.txt probe_ablation.txt kernel_time_by_size.txt time_by_occupancy.txt clock.txt valu_rate.txt issue_rate.txt; do
+for f in bench_n1.json bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt file_path.txt long_reads.txt scan_gaps.txt grid_sweep.txt dense_tables.txt host_ceiling.txt host_ceiling_flags.txt probe_ablation.txt kernel_time_by_size.txt time_by_occupancy.txt clock.txt valu_rate.txt issue_rate.txt; do
   echo "cp gpurun_out/$TAG/$f profiles/${TAG}_$f"
 done
 [[ $PART == *a* ]] && cat $O/bench_n1.json
