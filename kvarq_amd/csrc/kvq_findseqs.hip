@@ -26,6 +26,13 @@ int kvq_scan_finish_internal(kvq_scan *s);
 // ---------------------------------------------------------------------------
 
 static std::atomic<int> g_running{0}, g_stop{0}, g_sigints{0};
+static struct { kvq_table *t = nullptr; kvq_scan *s = nullptr; } g_kept;       // the last kvq_findseqs call's table and scan object (kvq_findseqs_free)
+static std::mutex g_kept_lock;
+void kvq_drop_kept_scan()
+{
+    std::lock_guard<std::mutex> l(g_kept_lock);
+    if (g_kept.s) { kvq_table *kt = g_kept.t; kvq_scan_destroy(g_kept.s); kvq_table_destroy(kt); g_kept.t = nullptr; g_kept.s = nullptr; }
+}
 static std::mutex g_live_lock;
 static struct {
     int64_t records = 0, parsed = 0, total = 0, longest = -1;
@@ -702,8 +709,11 @@ struct ScanSink {
         // publish the counters so far (engine.stats() may be polling), hand this batch over (its text sets out at once, the
         // kernels of the batch before it are enqueued: kvq_scan_host_async) and return, so that the reader fills the other
         // host buffer while this one crosses PCIe
+        // (only the head of the counter array -- scalars, read lengths, hits per sequence: 12 KB for the MTBC table -- not the
+        // coverage and mutation counters behind it, 0.8 MB: the blocking copy of all of it cost 5 % of a 3 GB file)
         if (have_live) {
-            if (hipMemcpy(ctr_live.data(), s->d_ctr, (size_t)s->t->ctr_len * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            const size_t head = (size_t)std::max<int64_t>(s->t->off_nseqbasehits + s->t->nseq, KVQ_CTR_READLENGTHS + KVQ_MAX_READLENGTH);
+            if (hipMemcpy(ctr_live.data(), s->d_ctr, std::min(head, (size_t)s->t->ctr_len) * 8, hipMemcpyDeviceToHost) != hipSuccess) {
                 kvq_set_error(KVQ_ERR_DEVICE, "device failure during scan"); return KVQ_ERR_DEVICE;
             }
             live_from_counters(s->t, ctr_live.data(), live_parsed, total);
@@ -769,8 +779,30 @@ extern "C" kvq_scan *kvq_findseqs(const char *const *files, int32_t nfiles,
     }
     g_stop = 0; g_sigints = 0;                                         // workhorse.c:1264-1265
     const double tf0 = now_ms();
-    kvq_table *t = kvq_table_create(seqs, seqlens, nseq, nullptr);
-    kvq_scan *s = t ? kvq_scan_create(t, nullptr) : nullptr;
+    // the table and the scan object of the last call are kept (kvq_findseqs_free): a caller that scans file after file with
+    // the same sequences and settings -- the usual case -- does not build the seed index and a dozen device buffers again
+    kvq_table *t = nullptr; kvq_scan *s = nullptr;
+    {
+        kvq_config cfg; kvq_config_get(&cfg);
+        std::lock_guard<std::mutex> l(g_kept_lock);
+        if (g_kept.s && nseq == g_kept.t->nseq && memcmp(&cfg, &g_kept.t->cfg, sizeof(cfg)) == 0) {
+            bool same = true;
+            for (int32_t i = 0; i < nseq && same; i++) {
+                const int32_t len = g_kept.t->h_off[i + 1] - g_kept.t->h_off[i];
+                same = seqlens[i] == len && memcmp(seqs[i], g_kept.t->h_tab.data() + g_kept.t->h_off[i], (size_t)len) == 0;
+            }
+            if (same && kvq_scan_reset(g_kept.s) == KVQ_OK) {
+                t = g_kept.t; s = g_kept.s; g_kept.t = nullptr; g_kept.s = nullptr;
+                s->tile_bytes = 0; s->rec_bytes = 0;                  // (another file: the tiles are sized from its own head)
+            }
+        }
+        if (!s && g_kept.s) { kvq_table *kt = g_kept.t; kvq_scan_destroy(g_kept.s); kvq_table_destroy(kt); g_kept.t = nullptr; g_kept.s = nullptr; }
+        kvq_clear_error();
+    }
+    if (!s) {
+        t = kvq_table_create(seqs, seqlens, nseq, nullptr);
+        s = t ? kvq_scan_create(t, nullptr) : nullptr;
+    }
     const double tf1 = now_ms();
     // the two pinned host buffers outlive the call: pinning and unpinning 130 MB costs more than
     // streaming a 1 GB file through them (only one findseqs runs at a time, g_running)
@@ -810,6 +842,12 @@ extern "C" void kvq_findseqs_free(kvq_scan *s)
 {
     if (!s) return;
     kvq_table *t = const_cast<kvq_table *>(s->t);
+    {
+        // kept for the next call with the same sequences and settings (one pair; KVQ_KEEP_SCAN=0: never)
+        static const bool keep = !(getenv("KVQ_KEEP_SCAN") && getenv("KVQ_KEEP_SCAN")[0] == '0');
+        std::lock_guard<std::mutex> l(g_kept_lock);
+        if (keep && t && !g_kept.s && s->finished) { g_kept.t = t; g_kept.s = s; return; }
+    }
     kvq_scan_destroy(s);
     kvq_table_destroy(t);
 }

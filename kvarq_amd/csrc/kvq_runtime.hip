@@ -95,7 +95,8 @@ static BlockCache g_dev_blocks((size_t)2 << 30, false), g_pin_blocks((size_t)512
 }
 
 // give the cached blocks back to the driver (a host that wants the memory; nothing needs calling this)
-extern "C" void kvq_release_cached(void) { g_dev_blocks.drop(); g_pin_blocks.drop(); }
+void kvq_drop_kept_scan();      // kvq_findseqs.hip
+extern "C" void kvq_release_cached(void) { kvq_drop_kept_scan(); g_dev_blocks.drop(); g_pin_blocks.drop(); }
 
 int DevBuf::ensure(size_t n)
 {

@@ -13,6 +13,7 @@ The scan itself runs only on the GPU: without the library or without a device
 ``findseqs`` raises, it never falls back to a CPU implementation.
 """
 import collections
+import itertools
 import numpy as np
 import ctypes as C
 
@@ -158,8 +159,10 @@ def findseqs(fname, sequences):
         # than the scan of a 3 GB file)
         def col(ptr, count):
             return np.ctypeslib.as_array(ptr, shape=(count,)).tolist() if count else []
-        hits = tuple(map(Hit, col(L.kvq_scan_hit_seq_nr(h), nh), col(L.kvq_scan_hit_file_pos(h), nh), col(L.kvq_scan_hit_seq_pos(h), nh),
-                         col(L.kvq_scan_hit_length(h), nh), col(L.kvq_scan_hit_readlength(h), nh)))
+        # (tuple.__new__(Hit, fields) is what Hit(*fields) ends up calling, without the Python-level frame in between)
+        hits = tuple(map(tuple.__new__, itertools.repeat(Hit),
+                         zip(col(L.kvq_scan_hit_seq_nr(h), nh), col(L.kvq_scan_hit_file_pos(h), nh), col(L.kvq_scan_hit_seq_pos(h), nh),
+                             col(L.kvq_scan_hit_length(h), nh), col(L.kvq_scan_hit_readlength(h), nh))))
         off = col(L.kvq_scan_hitseq_offsets(h), nh + 1)
         blob = C.string_at(L.kvq_scan_hitseq_blob(h), off[nh]) if nh else b''
         if as_str:
