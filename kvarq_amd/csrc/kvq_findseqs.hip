@@ -616,7 +616,8 @@ private:
 // driver
 // ---------------------------------------------------------------------------
 
-static const int64_t BATCH_BYTES = 64ll << 20;     // new stream bytes per batch
+// new stream bytes per batch (KVQ_BATCH_BYTES_MB: 16..512, read once; the two pinned buffers are of this size)
+static const int64_t BATCH_BYTES = [] { const char *e = getenv("KVQ_BATCH_BYTES_MB"); const long v = e ? atol(e) : 0; return (int64_t)(v >= 16 && v <= 512 ? v : 64) << 20; }();
 
 // Walk the files once: Sink::batch(data, nbytes, chunk offsets, nchunks, fpos,
 // parsed, total) is called for every run of whole chunks, in stream order.
