@@ -53,6 +53,30 @@ def test_findseqs_matches_reference_and_oracle(case, tmp_path):
     assert r['stats'] == o['stats']
 
 
+def test_the_scan_kept_between_findseqs_calls_is_as_good_as_new(tmp_path, monkeypatch):
+    """kvq_findseqs keeps its table and scan object for the next call with the same sequences and settings: files of
+    other record sizes, a changed setting, other sequences and the same ones again must all give the oracle's answer
+    (and the same with the keeping switched off)"""
+    g = synth.genome()
+    seqs = cases.mtbc_table()
+    files = {}
+    for name, (first, n, L) in dict(a=(0, 3000, 150), b=(5000, 2000, 300), c=(100, 4000, 75)).items():
+        f = tmp_path / (name + '.fastq'); f.write_bytes(synth.reads(g, first, n, L).tobytes()); files[name] = str(f)
+    plan = [('a', cases.PRODUCT, seqs), ('b', cases.PRODUCT, seqs), ('c', cases.PRODUCT, seqs), ('a', cases.PRODUCT, seqs),
+            ('a', dict(cases.PRODUCT, maxerrors=1), seqs), ('b', dict(cases.PRODUCT, maxerrors=1), seqs[:40]), ('b', cases.PRODUCT, seqs)]
+    want = [O.findseqs(files[f], q, **dict(cfg, nthreads=2)) for f, cfg, q in plan]
+    for keep in ('1', '0'):
+        monkeypatch.setenv('KVQ_KEEP_SCAN', keep)          # (read once per process: the second round repeats the first unless this process started with it)
+        for (f, cfg, q), o in zip(plan, want):
+            engine.config(**dict(cfg, nthreads=2))
+            r = engine.findseqs(files[f], q)
+            assert tuple(r['hits']) == tuple(o['hits']) and [bytes(h) for h in r['hitseqs']] == o['hitseqs'] and r['stats'] == o['stats'], (keep, f)
+    _lib.lib().kvq_release_cached()                        # (drops the kept pair and the cached blocks; the next call starts from nothing)
+    engine.config(**dict(cases.PRODUCT, nthreads=2))
+    r = engine.findseqs(files['a'], seqs)
+    assert tuple(r['hits']) == tuple(want[0]['hits']) and r['stats'] == want[0]['stats']
+
+
 def test_str_and_bytes_interfaces(fastqs):
     engine.config(**dict(cases.DEFAULTS, maxerrors=0, minoverlap=1000, minreadlength=3, Amin='!'))
     f = fastqs + '/test_engine.fastq'
