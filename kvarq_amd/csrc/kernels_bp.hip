@@ -1,9 +1,8 @@
-// kvarq_amd/csrc/kernels_bp.hip -- the fused seed-filter scan on bit-planes (the default scan
-// kernel; kernels_seeded.hip's text-in-LDS kernel stays selectable with KVQ_KERNEL=v1 and shares
-// the seed index, the tile geometry, the tile reports and the launch code with this one).
+// kvarq_amd/csrc/kernels_bp.hip -- the fused seed-filter scan on bit-planes, the scan kernel (kernels_seeded.hip
+// holds the seed index, the tile geometry and the tile reports; kvq_launch.hip launches it).
 //
-// Why planes: kvq_scan_seeded keeps the tile's text in LDS (80 KB per workgroup, 117 VGPRs), which
-// caps a CU at 16 waves, and it is latency bound (profiles/round1_pmc_sq_counters.txt: waves
+// Why planes: round 1's kernel kept the tile's text in LDS (80 KB per workgroup, 117 VGPRs), which
+// capped a CU at 16 waves, and it was latency bound (profiles/round1_pmc_sq_counters.txt: waves
 // parked 48 % of their cycles, vector pipes 38 % busy).  Here every byte of the text is looked at
 // once, in the registers it was fetched into, and LDS holds three bits per byte: "score >= Amin"
 // (1 bit) and the 2-bit base code (byte >> 1) & 3.  That is 15 KB instead of 40 KB per tile, so a

@@ -283,8 +283,6 @@ def test_well_formed_files_never_fall_back_to_the_exhaustive_kernels(tile, monke
     kernels -- the chunk's last tile, which often owns nothing but the final newline, used to be one)"""
     import os
     import random
-    if os.environ.get('KVQ_KERNEL') == 'planes' and tile is not None:
-        pytest.skip('KVQ_TILE sizes the tiles of the seed-filter kernel only')
     if tile is not None:
         monkeypatch.setenv('KVQ_TILE', tile)
     rng = random.Random(77)

@@ -20,9 +20,8 @@ s = scan.Scanner(t)
 for rep in range(2):
     s.reset(); s.scan_device(dd.ptr, n*rb, co); r = s.finish(hits=False)
 c = r['counters'][4+900:4+908].astype(np.float64)
-names = (['P1 planes+bar', 'P1b nl list+bar', 'P2', 'P3a trim+bar', 'P3b filter', 'bar after P3b', 'P4a+P4b+bars', 'tile end'] if os.environ.get('KVQ_KERNEL') == 'planes' else
-         ['P0 store+bar', 'P1a scan+bar', 'P1b write+bar', 'P2', 'P3 desc+trim', 'P3 filter', 'P4a+P4b (own queue)', 'tile-end barrier'])
-tile_bytes = 28672 if os.environ.get('KVQ_KERNEL') == 'planes' else int(os.environ.get('KVQ_TILE', 39760))   # what kvq_choose_tile picks for 150 bp records
+names = ['P0 store+bar', 'P1a scan+bar', 'P1b write+bar', 'P2', 'P3 desc+trim', 'P3 filter', 'P4a+P4b (own queue)', 'tile-end barrier']
+tile_bytes = int(os.environ.get('KVQ_TILE', 39760))   # what kvq_choose_tile picks for 150 bp records
 tot = c.sum()
 wgs = int(os.environ.get('KVQ_WGS', 1024))
 print('main kernel ms', r['main_kernel_ms'], 'tiles/WG', (n*rb/tile_bytes)/wgs)
