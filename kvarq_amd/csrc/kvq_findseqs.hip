@@ -26,7 +26,7 @@ int kvq_scan_finish_internal(kvq_scan *s);
 // ---------------------------------------------------------------------------
 
 static std::atomic<int> g_running{0}, g_stop{0}, g_sigints{0};
-static struct { kvq_table *t = nullptr; kvq_scan *s = nullptr; } g_kept;       // the last kvq_findseqs call's table and scan object (kvq_findseqs_free)
+static struct { kvq_table *t = nullptr; kvq_scan *s = nullptr; int dev = -1; } g_kept;       // the last kvq_findseqs call's table and scan object (kvq_findseqs_free)
 static std::mutex g_kept_lock;
 void kvq_drop_kept_scan()
 {
@@ -786,7 +786,8 @@ extern "C" kvq_scan *kvq_findseqs(const char *const *files, int32_t nfiles,
     {
         kvq_config cfg; kvq_config_get(&cfg);
         std::lock_guard<std::mutex> l(g_kept_lock);
-        if (g_kept.s && nseq == g_kept.t->nseq && memcmp(&cfg, &g_kept.t->cfg, sizeof(cfg)) == 0) {
+        int dev_now = 0; (void)hipGetDevice(&dev_now);
+        if (g_kept.s && g_kept.dev == dev_now && nseq == g_kept.t->nseq && memcmp(&cfg, &g_kept.t->cfg, sizeof(cfg)) == 0) {
             bool same = true;
             for (int32_t i = 0; i < nseq && same; i++) {
                 const int32_t len = g_kept.t->h_off[i + 1] - g_kept.t->h_off[i];
@@ -847,7 +848,7 @@ extern "C" void kvq_findseqs_free(kvq_scan *s)
         // kept for the next call with the same sequences and settings (one pair; KVQ_KEEP_SCAN=0: never)
         static const bool keep = !(getenv("KVQ_KEEP_SCAN") && getenv("KVQ_KEEP_SCAN")[0] == '0');
         std::lock_guard<std::mutex> l(g_kept_lock);
-        if (keep && t && !g_kept.s && s->finished) { g_kept.t = t; g_kept.s = s; return; }
+        if (keep && t && !g_kept.s && s->finished) { g_kept.t = t; g_kept.s = s; (void)hipGetDevice(&g_kept.dev); return; }
     }
     kvq_scan_destroy(s);
     kvq_table_destroy(t);
