@@ -169,7 +169,7 @@ def main():
             depth = 1
             ctrs = [torch.zeros(table.counters_len, dtype=torch.int64, device='cuda')]
             scanners = [scan.Scanner(table, ctrs[0].data_ptr())]
-            reduce_by = 'torch.distributed all_reduce (RCCL)'
+            reduce_by = 'torch.distributed all_reduce (%s)' % ('RCCL' if backend == 'nccl' else backend)
     else:
         scanners = [scan.Scanner(table) for _ in range(depth)]
     if args.exhaustive:
@@ -248,18 +248,26 @@ def main():
             total_hits = int(r['counters'][_lib.CTR_HITS])
             # the library's sum against an independent one (outside the timed region): every rank's OWN counters of
             # the last step, summed by torch.distributed, must equal what kvq_scan_finish left on this rank
+            # (a failure of this CHECK is reported in the line, not raised: the measurement above stands either way;
+            # every rank takes part in its collectives whatever it finds)
             import numpy as np
             import ctypes as C
-            own = np.zeros(table.counters_len, dtype=np.int64)
-            sc_last = scanners[(args.steps - 1) % depth]
-            assert L_.kvq_memcpy_d2h(own.ctypes.data_as(C.c_void_p), L_.kvq_scan_device_counters_own(sc_last.h), own.nbytes) == 0
-            chk = torch.from_numpy(own).to('cuda')
-            longest = chk[_lib.CTR_LONGEST].clone()
-            dist.all_reduce(chk, op=dist.ReduceOp.SUM); dist.all_reduce(longest, op=dist.ReduceOp.MAX)
-            chk[_lib.CTR_LONGEST] = longest
-            mine = torch.from_numpy(np.array(r['counters'], dtype=np.int64))
-            assert bool((chk.cpu() == mine).all()), 'the library\'s sum over the ranks differs from torch.distributed\'s'
-            join_checked = 'nseqhits, coverage and every other counter of the last step == torch.distributed sum of the ranks\' own counters'
+            try:
+                own = np.zeros(table.counters_len, dtype=np.int64)
+                sc_last = scanners[(args.steps - 1) % depth]
+                rc_own = L_.kvq_memcpy_d2h(own.ctypes.data_as(C.c_void_p), L_.kvq_scan_device_counters_own(sc_last.h), own.nbytes)
+                chk = torch.from_numpy(own).to('cuda')
+                longest = chk[_lib.CTR_LONGEST].clone()
+                dist.all_reduce(chk, op=dist.ReduceOp.SUM); dist.all_reduce(longest, op=dist.ReduceOp.MAX)
+                chk[_lib.CTR_LONGEST] = longest
+                mine = torch.from_numpy(np.array(r['counters'], dtype=np.int64))
+                same = rc_own == 0 and bool((chk.cpu() == mine).all())
+                join_checked = ('nseqhits, coverage and every other counter of the last step == torch.distributed sum of the ranks\' own counters'
+                                if same else 'MISMATCH: the library\'s sum over the ranks differs from torch.distributed\'s sum of the ranks\' own counters')
+            except Exception as e:                   # noqa: BLE001
+                join_checked = 'check not completed: %s' % e
+            if join_checked.startswith(('MISMATCH', 'check not')):
+                sys.stderr.write('bench.py: rank %d: %s\n' % (rank, join_checked))
         assert total_records == world * n, 'records lost: %d of %d' % (total_records, world * n)
     else:
         total_records = int(r['counters'][_lib.CTR_RECORDS])
