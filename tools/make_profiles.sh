@@ -26,6 +26,7 @@ python3 tools/pmc_traffic.py $O/fetch $O/write 10000000 325 > $O/pmc_traffic.jso
 python3 tools/pmc_sum.py $O/sq1 kvq_scan_ > $O/pmc_sq_counters.txt; python3 tools/pmc_sum.py $O/sq2 kvq_scan_ >> $O/pmc_sq_counters.txt
 python3 tools/trace_step.py $O/stats1 1 > $O/step_timeline.txt                 # one step at a time: the tail kernels at their own speed
 python3 tools/trace_step.py $O/stats 2 > $O/step_timeline_pipelined.txt        # the default: three steps in flight
+( echo '== three steps in flight (the default)'; python3 tools/kernel_agreement.py $O/stats $O/stats.log 5; echo '== one step at a time (--pipeline 1)'; python3 tools/kernel_agreement.py $O/stats1 $O/stats1.log 5 ) > $O/kernel_agreement.txt 2>&1
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/rocprofv3_kernel_stats.csv 2>/dev/null
 cp $(ls $O/stats1/*/*kernel_stats.csv | head -1) $O/rocprofv3_kernel_stats_pipeline1.csv 2>/dev/null
 step stamps; KVQ_DBG=16 timeout -k 10 200 python3 tools/phase_stamps.py > $O/phase_stamps.txt 2>&1
@@ -63,7 +64,7 @@ step bench;  cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json; timeout
 timeout -k 10 400 python3 bench.py --pipeline 1 --no-cpu-baseline --no-end-to-end > $O/bench_n1_pipeline1.json 2>> $O/bench.err
 fi
 step done
-for f in bench_n1.json bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt file_path.txt long_reads.txt scan_gaps.txt grid_sweep.txt dense_tables.txt host_ceiling.txt host_ceiling_flags.txt probe_ablation.txt kernel_time_by_size.txt time_by_occupancy.txt clock.txt valu_rate.txt issue_rate.txt; do
+for f in bench_n1.json kernel_agreement.txt bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt file_path.txt long_reads.txt scan_gaps.txt grid_sweep.txt dense_tables.txt host_ceiling.txt host_ceiling_flags.txt probe_ablation.txt kernel_time_by_size.txt time_by_occupancy.txt clock.txt valu_rate.txt issue_rate.txt; do
   echo "cp gpurun_out/$TAG/$f profiles/${TAG}_$f"
 done
 [[ $PART == *a* ]] && cat $O/bench_n1.json
