@@ -740,7 +740,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 auto tail_ok = [&](int jj) { const int pp = rl - (jj + 1) * SK; return mine && jj <= me_ && pp >= 0 && !((pp % SK) == 0 && pp <= me_ * SK); };
                 const bool hhit = fixed_block((int)gl * SK, head_ok((int)gl));
                 const bool thit = fixed_block(rl - ((int)gl + 1) * SK, tail_ok((int)gl));
-                constexpr int NR = SS == 8 ? 6 : SS == 4 ? 12 : 18;              // lookups per lane and round (18: a 150-base read's 72 even positions over four lanes)
+                constexpr int NR = SS == 8 ? 6 : SS == 4 ? 12 : (LG == 3 || LG == 1) ? 24 : 18;  // lookups per lane and round (18: a 150-base read's 72 even positions over four lanes; 24: a 300-base read's 147 over eight -- 19 a lane -- or a 100-base read's 47 over two, one round instead of two)
                 bool first = true;
                 for (int ee = e0; __any(ee < e1); ee += NR, first = false) {
                     const bool act = ee < e1;

@@ -103,18 +103,23 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         // the lane group of a read: four lanes, fixed at compile time, when that is the widest power of two
         // that gives every read of a full tile its own lanes (records of 100 to 250 bases); otherwise the
         // kernel that works the width out per tile
-        static const BpKernel kernels_bp[12] = { kvq_scan_bp<2, -1, false>, kvq_scan_bp<4, -1, false>, kvq_scan_bp<8, -1, false>,
+        static const BpKernel kernels_bp[18] = { kvq_scan_bp<2, -1, false>, kvq_scan_bp<4, -1, false>, kvq_scan_bp<8, -1, false>,
                                                  kvq_scan_bp<2, -1, true>, kvq_scan_bp<4, -1, true>, kvq_scan_bp<8, -1, true>,
                                                  kvq_scan_bp<2, 2, false>, kvq_scan_bp<4, 2, false>, kvq_scan_bp<8, 2, false>,
-                                                 kvq_scan_bp<2, 2, true>, kvq_scan_bp<4, 2, true>, kvq_scan_bp<8, 2, true> };
+                                                 kvq_scan_bp<2, 2, true>, kvq_scan_bp<4, 2, true>, kvq_scan_bp<8, 2, true>,
+                                                 kvq_scan_bp<2, 3, false>, kvq_scan_bp<4, 3, false>, kvq_scan_bp<8, 3, false>,
+                                                 kvq_scan_bp<2, 1, false>, kvq_scan_bp<4, 1, false>, kvq_scan_bp<8, 1, false> };
         static const int lg_env = getenv("KVQ_LG") ? atoi(getenv("KVQ_LG")) : -2;
         int lg = -1;
         if (s->rec_bytes >= 40u) {
             const uint32_t n_full = TILE / s->rec_bytes + 1u;                    // records a full tile can own
             if (n_full <= 128u && n_full > 64u) lg = 2;
+            else if (n_full <= 64u && n_full > 32u) lg = 3;                      // (eight lanes a read: records of 250 to 550 bases)
+            else if (n_full <= 256u && n_full > 128u) lg = 1;                    // (two lanes a read: records of 50 to 125 bases)
         }
-        if (lg_env >= -1) lg = lg_env == 2 ? 2 : -1;
-        hipLaunchKernelGGL(kernels_bp[(lg == 2 ? 6 : 0) + si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
+        if (lg_env >= -1) lg = lg_env >= 1 && lg_env <= 3 ? lg_env : -1;
+        if ((lg == 3 || lg == 1) && st) lg = -1;                                // (no instrumented build of those)
+        hipLaunchKernelGGL(kernels_bp[lg == 3 ? 12 + si : lg == 1 ? 15 + si : (lg == 2 ? 6 : 0) + si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
     }
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
     { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }              // (kvq_validate_tiles and what follows run beside the next scan)
