@@ -79,7 +79,23 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the file -> engine.findseqs -> Python result measurement behind the timed region')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of the CPU baseline sample')
+    ap.add_argument('--total-reads', type=int, default=0,
+                    help='records of the WHOLE job, split evenly over the ranks (strong scaling): `--gpus 8 --total-reads 40000000` is '
+                         'BASELINE.json configs[3]; without it every rank scans --reads records (weak scaling)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` by itself: this process becomes the launcher of N ranks (the join of the reference's
+        # worker threads, workhorse.c:1375-1447, is a join of processes here) and never touches the GPU
+        raise SystemExit(spawn_ranks(args.gpus))
+    if os.environ.get('KVQ_BENCH_CHILD_PROBE') == 'fail' and os.environ.get('RANK') == '1':
+        raise SystemExit(3)                         # (tests: a rank that dies takes the launcher's exit code with it)
+    if os.environ.get('KVQ_BENCH_CHILD_PROBE'):
+        # (tests/test_host_logic.py: what a rank is started with, printed before anything is imported)
+        print(json.dumps({'rank': int(os.environ.get('RANK', '0')), 'local_rank': int(os.environ.get('LOCAL_RANK', '0')),
+                          'world': int(os.environ.get('WORLD_SIZE', '1')), 'master': '%s:%s' % (os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT')),
+                          'gpu_modules_loaded': [m for m in ('torch', 'kvarq_amd._lib') if m in sys.modules]}))
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -112,6 +128,10 @@ def main():
     # ---- workload: resident in HBM before anything is timed -------------------
     L = args.readlen
     rb = synth.record_bytes(L)
+    if args.total_reads:
+        if args.total_reads % world:
+            raise SystemExit('--total-reads must be a multiple of the number of ranks')
+        args.reads = args.total_reads // world
     n = args.reads
     first = rank * n
     g = synth.genome()
@@ -274,6 +294,19 @@ def main():
         total_hits = r['n_hits']
         assert total_records == n, 'records lost: %d of %d' % (total_records, n)
 
+    # SURVEY 8(d) defines t_kernel as the sum of ALL device kernels of a scan: HIP events of the library around everything a
+    # step enqueues (table upload, tile tables, scan, validation, redo chain, fold, ordering, copies) only mean that when
+    # one step runs at a time, so five more steps are run strictly one after the other behind the timed region
+    all_ms = None
+    if args.steps > 0:
+        saved_depth, depth = depth, 1
+        try:
+            extra = run(5)
+            all_ms = sum(x['kernel_ms'] for x in extra) / len(extra)
+        finally:
+            depth = saved_depth
+        sync()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -287,10 +320,15 @@ def main():
     out = {
         'metric': 'fastq_reads_per_sec_scanned', 'value': value, 'unit': 'reads/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
-        'config': {'workload': '%d x %d bp synthetic FastQ per GPU (%d B/record, resident in HBM) vs %s table '
+        'higher_is_better': True, 'scaling': 'strong' if args.total_reads else 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+        'config': {'workload': '%s%d x %d bp synthetic FastQ per GPU (%d B/record, resident in HBM) vs %s table '
                                '(%d templates, both strands = %d sequences, %d bases); e=2, minoverlap=25, minreadlength=25, Amin=\'.\''
-                               % (n, L, rb, args.table, len(plus), len(seqs), sum(map(len, seqs))),
+                               % ('%d x %d bp in all, read-sharded over %d GPUs = ' % (args.total_reads, L, world) if args.total_reads else '',
+                                  n, L, rb, args.table, len(plus), len(seqs), sum(map(len, seqs))),
+                   'baseline_config': ('configs[3]' if args.total_reads == 40_000_000 and world == 8 and L == 150 and args.table == 'MTBC' else
+                                       'configs[2]' if n == 10_000_000 and L == 150 and args.table == 'MTBC' and args.table_scale == 1 else
+                                       'configs[1]' if n == 1_000_000 and L == 150 and args.table == 'MTBC' and args.table_scale == 1 else None),
+                   'total_reads': world * n,
                    'reads_per_gpu': n, 'readlen': L, 'table': args.table, 'table_scale': args.table_scale,
                    'parallelism': 'read-shard x%d, counter arrays summed by %s' % (world, reduce_by) if world > 1 else 'single GPU',
                    'kernel_path': 'exhaustive' if args.exhaustive or not any(table.seeded) else
@@ -305,7 +343,9 @@ def main():
                      'algorithmic_bytes_per_launch': bytes_per_launch,
                      # (HIP events around everything a step enqueues; with several steps in flight that span also holds the
                      # wait for the scan kernel in front, so it is only quoted for --pipeline 1)
-                     'all_kernels_ms_per_step': kern_ms / args.steps if depth == 1 else None},
+                     # every kernel and copy of a step (SURVEY 8d's t_kernel), from five steps run one at a time behind the timed region
+                     'all_kernels_ms_per_step': all_ms,
+                     'frac_all_kernels': (n * rb / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if all_ms else None},
     }
     # HBM bytes per launch of the dominant kernel from the PMC passes of this same command
     # (profiles/, collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes)
@@ -339,6 +379,54 @@ def main():
     sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would), relay what they print, return the first
+    non-zero exit code.  Runs BEFORE torch or libkvarq_hip are imported: the launcher never initialises the GPU (a process that
+    has must not be replaced or forked around on this pool), and it starts fresh interpreters rather than forking."""
+    import socket
+    import subprocess
+    loaded = [m for m in ('torch', 'kvarq_amd._lib') if m in sys.modules]
+    assert not loaded, 'the launcher must not have touched the GPU: %s' % loaded
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    sys.stderr.write('bench.py: launched %d ranks (pids %s) before any HIP call; rendezvous 127.0.0.1:%d\n' % (n, ' '.join(str(p.pid) for p in procs), port))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)      # (rank 0 prints the JSON line)
+    reader.start()
+    rc = 0
+    deadline = time.time() + 3600
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code and not rc:
+                rc = code
+                for q in pending:               # a rank has failed: the others would wait for it in a collective for ever
+                    q.terminate()
+        if pending:
+            if time.time() > deadline:
+                for q in pending:
+                    q.kill()
+                rc = rc or 124
+            time.sleep(0.05)
+    reader.join(10)
+    sys.stdout.write(b''.join(out0).decode())
+    sys.stdout.flush()
+    return rc
 
 
 def source_sha256():

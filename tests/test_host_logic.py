@@ -290,3 +290,26 @@ def test_sigint_is_counted_by_a_c_handler_and_the_old_handler_comes_back():
     with pytest.raises(KeyboardInterrupt):               # Python's handler is back
         os.kill(os.getpid(), signal.SIGINT)
         time.sleep(1)
+
+
+def test_bench_gpus_n_launches_n_ranks_before_any_hip_call():
+    """`python bench.py --gpus N` (the driver's command shape) is a complete N-rank run: the launcher starts N fresh
+    interpreters with the torch.distributed.run environment and has not loaded torch or libkvarq_hip itself -- the join
+    of the reference's worker threads (workhorse.c:1375-1447) as a join of processes"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, KVQ_BENCH_CHILD_PROBE='1')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--total-reads', '3000'],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert 'launched 3 ranks' in p.stderr and 'before any HIP call' in p.stderr
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line['rank'] == 0 and line['world'] == 3 and line['master'].startswith('127.0.0.1:')
+    assert line['gpu_modules_loaded'] == []
+    # a rank that fails takes the launcher's exit code with it
+    env['KVQ_BENCH_CHILD_PROBE'] = 'fail'
+    q = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env, capture_output=True, text=True, timeout=120)
+    assert q.returncode == 3

@@ -31,3 +31,7 @@ print('of the first phase: wait at the tile-top barrier %.0f, wait for the text 
 if os.environ.get('KVQ_KERNEL') != 'planes':
     w = r['counters'][4+908:4+916].astype(np.float64) / (n*rb/tile_bytes)
     print('P3+P4 cycles/tile by wave:', ' '.join('%.0f' % v for v in w))
+t = r['counters'][4+930:4+938].astype(np.float64)
+if t.sum() > 0:
+    print('P4 tallies per read: anchor candidates %.3f, fixed-block candidates %.3f, index entries tested %.3f, passed the 16-base test %.5f' % (t[0]/n, t[1]/n, t[2]/n, t[3]/n))
+    print('P4 per wave and stretch (%.0f stretches, %.2f reads each): candidate batches %.2f, rounds of the entry loop %.2f, byte-exact verifications %.3f' % (t[6], n/max(t[6],1), t[5]/max(t[6],1), t[4]/max(t[6],1), t[7]/max(t[6],1)))
