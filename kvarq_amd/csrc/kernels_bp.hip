@@ -98,55 +98,57 @@ __device__ __forceinline__ bool seed_live_bp(GlbWords tab2, uint32_t roff, int r
     return cdp_code8(roff + (uint32_t)rp) == (tab2_32(tab2, toff + (uint32_t)sq) & 0xFFFFu);
 }
 
-// One work item = one (candidate, index entry) pair = one diagonal of one read against one
-// sequence (the rules of verify_item in kernels_seeded.hip; the read's bytes come from global
-// memory, `text` = address of window offset 0).  Must be called by every lane of the wave.
+// What is left of a work item -- one (candidate, index entry) pair = one diagonal of one read against one sequence -- once its
+// sixteen bases have passed as 2-bit codes (0.02 per read, a true hit as a rule): which loops of the reference visit the diagonal,
+// the byte-exact count over the whole overlap (the read's bytes come from global memory, `text` = address of window offset 0),
+// the canonical discoverer, the emit.  Must be called by every lane of the wave.
 struct BpHot {                       // what the verification needs of the parameters
     const KvqParams *cold; GlbBytes tab; GlbWords tab2;
     int maxerrors, minoverlap;
 };
-__device__ __forceinline__ void verify_item_bp(const BpHot &P, const BpLds &S, GlbBytes text, bool active,
-                                               uint32_t rec, int p, uint32_t kind, uint64_t en, int64_t tile_fpos, int stride)
+__device__ __forceinline__ void bp_verify_rest(const BpHot &P, GlbBytes text, bool alive, uint32_t roff, int rl, int p, uint32_t kind,
+                                               uint32_t en_lo, uint32_t en_hi, int64_t tile_fpos, int stride)
 {
     bool hitAB = false, hitC = false;
-    int s = 0, rl = 0, lenAB = 0, lenC = 0, sposAB = 0, sposC = 0; uint32_t keyAB = 0, keyC = 0;
-    int64_t fpos = 0;
-    if (active) {
-        const uint32_t ri = S.rinfo[rec];
-        const uint32_t roff = ri & 0xFFFFu; rl = (int)(ri >> 16);
-        fpos = tile_fpos + (int64_t)roff - (int64_t)ST_PRE;
-        const int q = (int)(en & 4095u);
-        s = (int)((en >> 12) & 0xFFFFFu);
-        const uint32_t toff = (uint32_t)((en >> 32) & 0xFFFFFu);
-        const int seql = (int)(en >> 52);
+    int s = 0, lenAB = 0, lenC = 0, sposAB = 0, sposC = 0; uint32_t keyAB = 0, keyC = 0;
+    const int64_t fpos = tile_fpos + (int64_t)roff - (int64_t)ST_PRE;
+    if (alive) {
+        const int q = (int)(en_lo & 4095u);
+        s = (int)(en_lo >> 12);
+        const uint32_t toff = en_hi & 0xFFFFFu;
+        const int seql = (int)(en_hi >> 20);
         const int mo = P.minoverlap, me = P.maxerrors;
         const int d = q - p;                             // sequence index = read index + d
         const int a = d < 0 ? -d : 0;
         const int L = (rl < seql - d ? rl : seql - d) - a;
-        // most false candidates die here, on the first 16 bases of the diagonal: compared as 2-bit
-        // codes (bytes that are equal have equal codes: this never rejects what the bytes accept)
-        bool alive = L > 0;
-        if (alive && L >= 16) alive = diff_codes(cdp32(roff + (uint32_t)a), tab2_32(P.tab2, toff + (uint32_t)(a + d))) <= me;
         // which reference loops visit this diagonal
         bool canAB = false, canC = false;
         const bool guard = rl > mo && seql > mo;
-        if (alive) {
-            if (d < 0) {
-                const int i = -d;
-                if (i <= rl - seql) { canC = true; lenC = seql; sposC = -i; keyC = (2u << 30) | (uint32_t)i; }              // 1147
-                else if (guard && i <= rl - mo) { canAB = true; lenAB = rl - i; sposAB = -i; keyAB = (0u << 30) | (uint32_t)(rl - mo - i); }   // 1116
-            } else if (d == 0) {
-                canC = true; lenC = rl > seql ? seql : rl; sposC = 0; keyC = 2u << 30;                                         // 1147 / 1163
-            } else {
-                const int i = d;
-                if (guard && i <= seql - mo && i >= seql - rl) { canAB = true; lenAB = seql - i; sposAB = i; keyAB = (1u << 30) | (uint32_t)(seql - mo - i); }   // 1130
-                if (rl <= seql && i <= seql - rl) { canC = true; lenC = rl; sposC = i; keyC = (2u << 30) | (uint32_t)i; }       // 1163
-            }
+        if (d < 0) {
+            const int i = -d;
+            if (i <= rl - seql) { canC = true; lenC = seql; sposC = -i; keyC = (2u << 30) | (uint32_t)i; }              // 1147
+            else if (guard && i <= rl - mo) { canAB = true; lenAB = rl - i; sposAB = -i; keyAB = (0u << 30) | (uint32_t)(rl - mo - i); }   // 1116
+        } else if (d == 0) {
+            canC = true; lenC = rl > seql ? seql : rl; sposC = 0; keyC = 2u << 30;                                         // 1147 / 1163
+        } else {
+            const int i = d;
+            if (guard && i <= seql - mo && i >= seql - rl) { canAB = true; lenAB = seql - i; sposAB = i; keyAB = (1u << 30) | (uint32_t)(seql - mo - i); }   // 1130
+            if (rl <= seql && i <= seql - rl) { canC = true; lenC = rl; sposC = i; keyC = (2u << 30) | (uint32_t)i; }       // 1163
         }
         if (canAB || canC) {
             // byte-exact mismatch count of the whole overlap
             int mism = 0, j = 0;
             const GlbBytes x = text + roff + (uint32_t)a, y = P.tab + toff + (uint32_t)(a + d);
+            // (eight bytes a step while they last: what comes here is a true hit as a rule, the whole overlap gets compared, and a step is one
+            // trip to memory -- four bytes a step made a 150-base hit 38 dependent trips, for which the other seven waves waited at the tile's end;
+            // sixteen a step cost the kernel four registers it does not have)
+            for (; j + 8 <= L && mism <= me; j += 8) {
+                typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                typedef u32x2_t __attribute__((aligned(1))) u32x2_any;
+                const u32x2_t xv = *reinterpret_cast<const __attribute__((address_space(1))) u32x2_any *>(x + j);
+                const u32x2_t yv = *reinterpret_cast<const __attribute__((address_space(1))) u32x2_any *>(y + j);
+                mism += diff_bytes(xv.x, yv.x) + diff_bytes(xv.y, yv.y);
+            }
             for (; j + 4 <= L && mism <= me; j += 4) mism += diff_bytes(glb_u32(x + j), glb_u32(y + j));
             for (; j < L && mism <= me; j++) mism += (x[j] != y[j]);
             if (mism <= me) {
@@ -811,35 +813,12 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 BSTAMP(5);
                 KVQ_SETPRIO(3);
 
-                // ---- P4a: one candidate per lane: index range -> (candidate, entry) work items ----
-                const bool over1 = qn > BP_QW;                            // candidates were dropped
-                const uint32_t qn_ok = (over1 || (dbg & 1u)) ? 0u : qn;
-                uint32_t q2n = 0;
-                BpHot H = {}; GlbWords start_anc = nullptr, start_all = nullptr; const __attribute__((address_space(1))) uint64_t *ent_anc = nullptr, *ent_all = nullptr;
-                int64_t tile_fpos = 0;
-                if (qn_ok) {
-                    const BpArgsPtr A = bp_args(A_);
-                    H.cold = &A_->P; H.tab = (GlbBytes)A->P.tab; H.tab2 = (GlbWords)A->X.tab2; H.maxerrors = me_; H.minoverlap = A->P.minoverlap;
-                    start_anc = (GlbWords)A->X.start_anc; start_all = (GlbWords)A->X.start_all;
-                    ent_anc = (const __attribute__((address_space(1))) uint64_t *)A->X.ent_anc; ent_all = (const __attribute__((address_space(1))) uint64_t *)A->X.ent_all;
-                    tile_fpos = A->fpos_base + (int64_t)g0;
-                }
-                for (uint32_t q0 = 0; q0 < qn_ok; q0 += 64u) {
-                    const uint32_t qi = q0 + lane;
-                    uint32_t en0 = 0, ne = 0;
-                    if (qi < qn_ok) {
-                        const uint32_t cd = q1[qi];
-                        const uint32_t code = cdp_code8((S.rinfo[cd & 511u] & 0xFFFFu) + ((cd >> 9) & 0xFFFFu));
-                        const GlbWords st = (cd >> BP_Q1_KIND) ? start_all : start_anc;
-                        en0 = st[code]; ne = st[code + 1u] - en0;
-                    }
-                    const uint32_t inc = kvq_wave_incl_scan(ne);
-                    const uint32_t base = q2n + inc - ne;
-                    for (uint32_t j = 0; j < ne; j++)
-                        if (base + j < BP_Q2W) q2[base + j] = (qi << 22) | (en0 + j);
-                    q2n += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                }
-                const bool over = over1;                                  // (work items never run over: they are dealt with a queue-full at a time, below)
+                // ---- P4: candidates -> (candidate, index entry) work items, one per lane -> a window of sixteen bases of the diagonal
+                // as 2-bit codes against the entry's own copy of the sequence around the seed (SeedEntry::ctx; equal bytes have equal
+                // codes, so this only ever rejects, and nearly every false candidate ends here: TWO dependent loads, code -> range of
+                // entries -> entry; round 3 went on to the 2-bit table for the bases) -> what is left goes through bp_verify_rest ----
+                const bool over = qn > BP_QW;                             // candidates were dropped
+                const uint32_t qn_ok = (over || (dbg & 1u)) ? 0u : qn;
                 if (over && step > 1u) { step >>= 1; continue; }
                 if (over) {
                     // ONE read has more candidates than the queue holds (step == 1): it alone goes to the exhaustive matcher behind the scan (the redo's
@@ -864,30 +843,21 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                         else atomicOr(A->fail, 2u);                      // (reported as records that went through the exhaustive kernels; the next launches of this scan object use the wide grids)
                     }
                 }
-
-        KVQ_MARK("P4b");
-                // ---- P4b: one work item per lane ----
-                auto verify_queue = [&](uint32_t n_items) {
-                    for (uint32_t i0 = 0; i0 < n_items; i0 += 64u) {
-                        const uint32_t ii = i0 + lane;
-                        const bool active = ii < n_items;
-                        uint32_t rec = 0, kind = 0; int p = 0; uint64_t en = 0;
-                        if (active) {
-                            const uint32_t it = q2[ii];
-                            const uint32_t cd = q1[it >> 22];
-                            rec = cd & 511u; p = (int)((cd >> 9) & 0xFFFFu); kind = cd >> BP_Q1_KIND;
-                            en = (kind ? ent_all : ent_anc)[it & 0x3FFFFFu];
-                        }
-                        verify_item_bp(H, S, text, active, rec, p, kind, en, tile_fpos, SS);
+                if (qn_ok) {
+                    typedef const __attribute__((address_space(1))) u32x4_t *GlbEntries;
+                    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                    typedef const __attribute__((address_space(1))) u32x2_t __attribute__((aligned(4))) *GlbPairs;
+                    BpHot H; GlbWords start; GlbEntries ent; int64_t tile_fpos; int need;
+                    {
+                        const BpArgsPtr A = bp_args(A_);
+                        H.cold = &A_->P; H.tab = (GlbBytes)A->P.tab; H.tab2 = (GlbWords)A->X.tab2; H.maxerrors = me_; H.minoverlap = A->P.minoverlap;
+                        start = (GlbWords)A->X.start; ent = (GlbEntries)A->X.ent;
+                        tile_fpos = A->fpos_base + (int64_t)g0;
+                        need = (me_ + 1) * SK;                            // no alignment is shorter (kvq_seed_index_build)
                     }
-                };
-                verify_queue(q2n < BP_Q2W ? q2n : BP_Q2W);
-                // (dense tables: a read that matches dozens of sequences has more work items than the queue holds.  The items
-                // are numbered in candidate order, the queue has taken the first BP_Q2W; for every further queue-full [w0, w0 +
-                // BP_Q2W) the candidates, a hundred at most, are simply walked again)
-                if (__builtin_expect(q2n > BP_Q2W, 0)) {
-                    const uint32_t total = q2n;
-                    for (uint32_t w0 = BP_Q2W; w0 < total; w0 += BP_Q2W) {
+                    // (the items are numbered in candidate order; the queue takes BP_Q2W of them a round -- one round, unless a read matches
+                    // dozens of sequences of a dense table: then the candidates, a hundred at most, are simply walked again for the next window)
+                    for (uint32_t w0 = 0; ; w0 += BP_Q2W) {
                         uint32_t run = 0;
                         for (uint32_t q0 = 0; q0 < qn_ok; q0 += 64u) {
                             const uint32_t qi = q0 + lane;
@@ -895,8 +865,8 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                             if (qi < qn_ok) {
                                 const uint32_t cd = q1[qi];
                                 const uint32_t code = cdp_code8((S.rinfo[cd & 511u] & 0xFFFFu) + ((cd >> 9) & 0xFFFFu));
-                                const GlbWords st = (cd >> BP_Q1_KIND) ? start_all : start_anc;
-                                en0 = st[code]; ne = st[code + 1u] - en0;
+                                const u32x2_t st = *(GlbPairs)(start + (code | ((cd >> BP_Q1_KIND) << 16)));      // (the ALL index's codes follow the anchors')
+                                en0 = st.x; ne = st.y - st.x;
                             }
                             const uint32_t inc = kvq_wave_incl_scan(ne);
                             const uint32_t base = run + inc - ne - w0;                          // (unsigned: items in front of w0 wrap beyond the queue)
@@ -904,7 +874,39 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                                 if (base + j < BP_Q2W) q2[base + j] = (qi << 22) | (en0 + j);
                             run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                         }
-                        verify_queue(total - w0 < BP_Q2W ? total - w0 : BP_Q2W);
+        KVQ_MARK("P4b");
+                        const uint32_t n_items = run - w0 < BP_Q2W ? run - w0 : BP_Q2W;
+                        for (uint32_t i0 = 0; i0 < n_items; i0 += 64u) {
+                            const uint32_t ii = i0 + lane;
+                            bool alive = false;
+                            uint32_t kind = 0, croff = 0, en_lo = 0, en_hi = 0; int p = 0, crl = 0;
+                            if (ii < n_items) {
+                                const uint32_t it = q2[ii];
+                                const u32x4_t E = ent[it & 0x3FFFFFu];
+                                const uint32_t cd = q1[it >> 22];
+                                p = (int)((cd >> 9) & 0xFFFFu); kind = cd >> BP_Q1_KIND;
+                                const uint32_t ri = S.rinfo[cd & 511u];
+                                croff = ri & 0xFFFFu; crl = (int)(ri >> 16);
+                                en_lo = E.x; en_hi = E.y;
+                                const int q = (int)(E.x & 4095u), seql = (int)(E.y >> 20);
+                                const int d = q - p;                     // sequence index = read index + d
+                                const int a = d < 0 ? -d : 0;
+                                const int L = (crl < seql - d ? crl : seql - d) - a;
+                                if (L >= need) {
+                                    // a window of min(L, 16) bases of the diagonal that lies inside the entry's 32: at the seed, or flush with the end of the overlap
+                                    const int wn = L < 16 ? L : 16;
+                                    const int w = p < a + L - wn ? p : a + L - wn;
+                                    const uint32_t sh = 2u * (uint32_t)(w - p + 16);          // 0 .. 32
+                                    const uint32_t seqw = (uint32_t)((((uint64_t)E.w << 32) | E.z) >> sh);
+                                    const uint32_t v = cdp32(croff + (uint32_t)w) ^ seqw;
+                                    uint32_t dm = (v | (v >> 1)) & 0x55555555u;
+                                    if (wn < 16) dm &= (1u << (2 * wn)) - 1u;
+                                    alive = __popc(dm) <= me_;
+                                }
+                            }
+                            if (__any(alive)) bp_verify_rest(H, text, alive, croff, crl, p, kind, en_lo, en_hi, tile_fpos, SS);
+                        }
+                        if (run <= w0 + BP_Q2W) break;
                     }
                 }
                 KVQ_SETPRIO(2);

@@ -46,18 +46,23 @@
 #define TR_FLAG_PARTIAL 0x8000000u    // ... but it did scan the records in front of those (so its speculated first record counts, and is checked)
 #define KVQ_SKIP_CAP 1024u            // skipped tiles a batch may have before it is scanned again as a whole
 
+// One index entry (16 bytes), the same for both indexes: which sequence position carries the 8-mer, and the 32 sequence bases
+// around it as 2-bit codes -- whatever 16-base window of the diagonal the kernel picks for its first test lies inside them, so
+// a work item is dismissed without a third dependent load (round 3: code -> CSR start -> entry -> 2-bit table).
+//   en  = position in sequence (12) | sequence number (20) | table offset of the sequence (20) | its length (12)
+//   ctx = codes of sequence bases [pos - 16, pos + 16), base i of them in bits 2i, 2i + 1 (zero outside the sequence)
+struct SeedEntry { uint64_t en, ctx; };
 struct SeedTables {
     const uint32_t *bm1;                      // two bitmaps of 8 KiB, one bit per 8-mer code: anchor blocks, then anywhere in a sequence
-    const uint32_t *start_anc, *start_all;    // CSR starts, 65537 entries
-    // entry: position in sequence (12) | sequence number (20) | table offset of the sequence (20) | its length (12)
-    const uint64_t *ent_anc, *ent_all;
+    const uint32_t *start;                    // CSR starts into ent[]: slot code for the anchor index, 65536 + code for the index of all positions (131073 entries)
+    const SeedEntry *ent;                     // the entries of both indexes, the anchors' first
     const uint32_t *tab2;                     // the sequence table as 2-bit codes, 16 bases per word (kernels_bp.hip)
     int32_t stride;                           // read positions 0, stride, 2*stride, ... are looked up for anchors (2, 4 or 8)
 };
 
 struct SeedIndex {
     int stride = 2;           // anchor blocks sit at sequence offsets 8j + 0 .. 8j + stride - 1
-    DevBuf d_bm1, d_start_anc, d_start_all, d_ent_anc, d_ent_all, d_tab2;
+    DevBuf d_bm1, d_start, d_ent, d_tab2;
     SeedTables dev;
 };
 
@@ -102,31 +107,40 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     int stride = minlen >= need + 7 ? 8 : minlen >= need + 3 ? 4 : 2;
     if (const char *sv = getenv("KVQ_STRIDE")) { const int w = atoi(sv); if ((w == 2 || w == 4 || w == 8) && w <= stride) stride = w; }
 
-    std::vector<std::pair<uint32_t, uint64_t>> anc, all;       // (code, entry)
+    struct Ent { uint32_t key; SeedEntry e; };                  // key = code, + 65536 for the index of all positions
+    std::vector<Ent> v;
     for (int s : t->seeded) {
         const uint8_t *q = &t->h_tab[t->h_off[s]];
         const int len = t->h_off[s + 1] - t->h_off[s];
         const uint64_t hi = ((uint64_t)(uint32_t)t->h_off[s] << 32) | ((uint64_t)(uint32_t)len << 52) | ((uint64_t)(uint32_t)s << 12);
+        auto entry = [&](int pos, uint32_t all) -> Ent {
+            uint64_t ctx = 0;
+            for (int i = 0; i < 32; i++) { const int sp = pos - 16 + i; if (sp >= 0 && sp < len) ctx |= (uint64_t)code2_of(q[sp]) << (2 * i); }
+            return Ent{ host_code8(q + pos) + (all << 16), SeedEntry{ hi | (uint64_t)pos, ctx } };
+        };
         for (int j = 0; j <= e; j++)
-            for (int sft = 0; sft < stride; sft++) anc.emplace_back(host_code8(q + j * SK + sft), hi | (uint64_t)(j * SK + sft));
-        for (int p = 0; p + SK <= len; p++) all.emplace_back(host_code8(q + p), hi | (uint64_t)p);
+            for (int sft = 0; sft < stride; sft++) v.push_back(entry(j * SK + sft, 0u));
+        for (int p = 0; p + SK <= len; p++) v.push_back(entry(p, 1u));
+    }
+    if (v.size() >= (1u << 22)) {
+        // (a work item of the scan kernel names its entry with 22 bits: a table this large goes to the exhaustive kernels as a whole)
+        t->seeded.clear(); std::fill(t->is_seeded.begin(), t->is_seeded.end(), 0); t->seed_k = 0;
+        return nullptr;
     }
     SeedIndex *ix = new SeedIndex();
     ix->stride = stride;
     std::vector<uint8_t> bm1(16384, 0);
-    auto upload = [&](std::vector<std::pair<uint32_t, uint64_t>> &v, int bit, DevBuf &st, DevBuf &en) -> bool {
-        std::sort(v.begin(), v.end());
-        std::vector<uint32_t> start(65537, 0); std::vector<uint64_t> ent(v.size() + 1, 0);
-        for (size_t i = 0; i < v.size(); i++) {
-            bm1[(size_t)bit * 8192 + (v[i].first >> 3)] |= (uint8_t)(1u << (v[i].first & 7));
-            start[v[i].first + 1]++; ent[i] = v[i].second;
-        }
-        for (int c = 0; c < 65536; c++) start[c + 1] += start[c];
-        return st.ensure(65537 * 4) == KVQ_OK && en.ensure(ent.size() * 8) == KVQ_OK &&
-               hipMemcpy(st.p, start.data(), 65537 * 4, hipMemcpyHostToDevice) == hipSuccess &&
-               hipMemcpy(en.p, ent.data(), ent.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
-    };
-    if (!upload(anc, 0, ix->d_start_anc, ix->d_ent_anc) || !upload(all, 1, ix->d_start_all, ix->d_ent_all) ||
+    std::stable_sort(v.begin(), v.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
+    std::vector<uint32_t> start(131073 + 1, 0); std::vector<SeedEntry> ent(v.size() + 1, SeedEntry{ 0, 0 });
+    for (size_t i = 0; i < v.size(); i++) {
+        bm1[v[i].key >> 3] |= (uint8_t)(1u << (v[i].key & 7));                  // (bit 16 of the key = the second bitmap)
+        start[v[i].key + 1]++; ent[i] = v[i].e;
+    }
+    for (int c = 0; c < 131072; c++) start[c + 1] += start[c];
+    start[131073] = start[131072];
+    if (ix->d_start.ensure(start.size() * 4) != KVQ_OK || ix->d_ent.ensure(ent.size() * sizeof(SeedEntry)) != KVQ_OK ||
+        hipMemcpy(ix->d_start.p, start.data(), start.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ix->d_ent.p, ent.data(), ent.size() * sizeof(SeedEntry), hipMemcpyHostToDevice) != hipSuccess ||
         ix->d_bm1.ensure(16384) != KVQ_OK || hipMemcpy(ix->d_bm1.p, bm1.data(), 16384, hipMemcpyHostToDevice) != hipSuccess) {
         if (!kvq_error_code()) kvq_set_error(KVQ_ERR_DEVICE, "uploading the seed index failed");
         kvq_seed_index_destroy(ix);
@@ -145,8 +159,7 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
         }
         ix->dev.tab2 = ix->d_tab2.as<uint32_t>();
     }
-    ix->dev.start_anc = ix->d_start_anc.as<uint32_t>(); ix->dev.start_all = ix->d_start_all.as<uint32_t>();
-    ix->dev.ent_anc = ix->d_ent_anc.as<uint64_t>(); ix->dev.ent_all = ix->d_ent_all.as<uint64_t>();
+    ix->dev.start = ix->d_start.as<uint32_t>(); ix->dev.ent = ix->d_ent.as<SeedEntry>();
     ix->dev.stride = stride;
     return ix;
 }
@@ -154,7 +167,7 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
 void kvq_seed_index_destroy(SeedIndex *ix)
 {
     if (!ix) return;
-    DevBuf *b[] = { &ix->d_tab2, &ix->d_bm1, &ix->d_start_anc, &ix->d_start_all, &ix->d_ent_anc, &ix->d_ent_all };
+    DevBuf *b[] = { &ix->d_tab2, &ix->d_bm1, &ix->d_start, &ix->d_ent };
     for (DevBuf *x : b) x->release();
     delete ix;
 }
