@@ -336,7 +336,8 @@ __device__ __forceinline__ void bp_runs64(uint64_t m, int n, uint32_t dbg, int &
 // 512 >> LG reads takes several passes); LG < 0: the widest group that gives every read of the tile its
 // own lanes in one pass, worked out per tile.  The launch picks LG = 2 when that is what the records of
 // the text ask for (100 to 250 bases), the general kernel otherwise.
-template <int SS, int LG, bool STAMPS>
+// DIAG: the kernel honours the KVQ_DBG switches (ablations, forced paths); the production instantiations do not carry them
+template <int SS, int LG, bool STAMPS, bool DIAG = STAMPS>
 __global__ void __launch_bounds__(ST_THREADS, BP_OCC)
 kvq_scan_bp(const BpArgs *__restrict__ A_)
 {
@@ -354,7 +355,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     uint32_t ntiles, tile_bytes, dbg, amin;
     {
         const BpArgsPtr A = bp_args(A_);
-        ntiles = A->ntiles; tile_bytes = A->tile_bytes; dbg = A->dbg; amin = (uint32_t)A->P.amin;
+        ntiles = A->ntiles; tile_bytes = A->tile_bytes; dbg = DIAG ? A->dbg : 0u; amin = (uint32_t)A->P.amin;
         const GlbWords bm1 = (GlbWords)A->X.bm1;
         for (int i = tid; i < 2048; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = bm1[i];
     }
@@ -758,9 +759,13 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                         uint32_t R[NW - 1];
 #pragma unroll
                         for (int t = 0; t < NW - 1; t++) R[t] = __builtin_amdgcn_alignbit(W[t + 1], W[t], bo);
+                        // (round 4: a lookup in six two-cycle instructions instead of four four-cycle ones -- the bitmap is read a word at a time, the
+                        // shift that brings the code's bit down takes its five low bits from the code itself, and the hits are shifted in from the
+                        // last lookup to the first by an add and a three-input logic op: no v_bfe, no v_lshl_or)
                         constexpr int NB = 6;
+                        static_assert(NR % NB == 0, "whole batches of lookups");
 #pragma unroll
-                        for (int j0 = 0; j0 < NR; j0 += NB) {
+                        for (int j0 = NR - NB; j0 >= 0; j0 -= NB) {
                             uint32_t bi[NB], bb[NB];
 #pragma unroll
                             for (int u = 0; u < NB; u++) {
@@ -768,12 +773,16 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                                 // the code is bits o .. o + 15 of R[wj] (and of R[wj + 1] when it crosses the word)
                                 const uint32_t word = o <= 16 ? R[wj] : __builtin_amdgcn_alignbit(R[wj + 1 < NW - 1 ? wj + 1 : wj], R[wj], 16);
                                 const uint32_t off = (uint32_t)(o <= 16 ? o : o - 16);
-                                bi[u] = __builtin_amdgcn_ubfe(word, off, 3u);
-                                bb[u] = lds_byte_at(BP_LDS_BMA + __builtin_amdgcn_ubfe(word, off + 3u, 13u));
+                                bi[u] = word >> off;                                                        // (its low five bits: the code's)
+                                bb[u] = lds_u32_at(BP_LDS_BMA + ((word >> (off + 3u)) & 0x1FFCu));          // the bitmap word of code >> 5
                             }
                             asm volatile("" ::: "memory");
 #pragma unroll
-                            for (int u = 0; u < NB; u++) hA |= __builtin_amdgcn_ubfe(bb[u], bi[u], 1u) << (j0 + u);
+                            for (int u = NB - 1; u >= 0; u--) {
+                                uint32_t h2;
+                                asm("v_add_u32 %0, %1, %1" : "=v"(h2) : "v"(hA));                            // (hA << 1 by the two-cycle adder: the compiler's v_lshlrev takes four)
+                                hA = __builtin_amdgcn_bitop3_b32(h2, bb[u] >> (bi[u] & 31u), 1u, 0xF8);      // a | (b & c)
+                            }
                         }
                     }
                     const int nv = act ? (e1 - ee < NR ? e1 - ee : NR) : 0;

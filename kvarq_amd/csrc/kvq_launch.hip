@@ -103,6 +103,9 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         // the lane group of a read: four lanes, fixed at compile time, when that is the widest power of two
         // that gives every read of a full tile its own lanes (records of 100 to 250 bases); otherwise the
         // kernel that works the width out per tile
+        // (with a KVQ_DBG switch set: the instantiations that honour them -- the general kernel and the four-lane one)
+        static const BpKernel kernels_diag[6] = { kvq_scan_bp<2, -1, false, true>, kvq_scan_bp<4, -1, false, true>, kvq_scan_bp<8, -1, false, true>,
+                                                  kvq_scan_bp<2, 2, false, true>, kvq_scan_bp<4, 2, false, true>, kvq_scan_bp<8, 2, false, true> };
         static const BpKernel kernels_bp[18] = { kvq_scan_bp<2, -1, false>, kvq_scan_bp<4, -1, false>, kvq_scan_bp<8, -1, false>,
                                                  kvq_scan_bp<2, -1, true>, kvq_scan_bp<4, -1, true>, kvq_scan_bp<8, -1, true>,
                                                  kvq_scan_bp<2, 2, false>, kvq_scan_bp<4, 2, false>, kvq_scan_bp<8, 2, false>,
@@ -119,7 +122,9 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         }
         if (lg_env >= -1) lg = lg_env >= 1 && lg_env <= 3 ? lg_env : -1;
         if ((lg == 3 || lg == 1) && st) lg = -1;                                // (no instrumented build of those)
-        hipLaunchKernelGGL(kernels_bp[lg == 3 ? 12 + si : lg == 1 ? 15 + si : (lg == 2 ? 6 : 0) + si + st], dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
+        if ((dbg & ~16u) && !st && lg != 2) lg = -1;
+        const BpKernel kern = ((dbg & ~16u) && !st) ? kernels_diag[(lg == 2 ? 3 : 0) + si] : kernels_bp[lg == 3 ? 12 + si : lg == 1 ? 15 + si : (lg == 2 ? 6 : 0) + si + st];
+        hipLaunchKernelGGL(kern, dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
     }
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
     { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }              // (kvq_validate_tiles and what follows run beside the next scan)
