@@ -75,7 +75,7 @@ __device__ __forceinline__ uint32_t cdp32(uint32_t pos)
     const uint32_t a = (pos >> 2) & ~3u, sh = (pos & 15u) * 2u;
     return __builtin_amdgcn_alignbit(lds_u32_at(a + 4u), lds_u32_at(a), sh);
 }
-__device__ __forceinline__ uint32_t cdp_code8(uint32_t pos) { return cdp32(pos) & 0xFFFFu; }
+template <int KK> __device__ __forceinline__ uint32_t cdp_code(uint32_t pos) { return cdp32(pos) & ((1u << (2 * KK)) - 1u); }      // the K-mer code of the bases from window byte `pos` on
 
 // the same for the 2-bit copy of the sequence table in global memory
 typedef const __attribute__((address_space(1))) uint32_t *GlbWords;
@@ -92,10 +92,11 @@ __device__ __forceinline__ int diff_codes(uint32_t x, uint32_t y)
     return __popc((v | (v >> 1)) & 0x55555555u);
 }
 
+template <int KK>
 __device__ __forceinline__ bool seed_live_bp(GlbWords tab2, uint32_t roff, int rl, int rp, uint32_t toff, int seql, int sq)
 {
-    if (rp < 0 || rp + SK > rl || sq < 0 || sq + SK > seql) return false;
-    return cdp_code8(roff + (uint32_t)rp) == (tab2_32(tab2, toff + (uint32_t)sq) & 0xFFFFu);
+    if (rp < 0 || rp + KK > rl || sq < 0 || sq + KK > seql) return false;
+    return cdp_code<KK>(roff + (uint32_t)rp) == (tab2_32(tab2, toff + (uint32_t)sq) & ((1u << (2 * KK)) - 1u));
 }
 
 // What is left of a work item -- one (candidate, index entry) pair = one diagonal of one read against one sequence -- once its
@@ -104,8 +105,9 @@ __device__ __forceinline__ bool seed_live_bp(GlbWords tab2, uint32_t roff, int r
 // the canonical discoverer, the emit.  Must be called by every lane of the wave.
 struct BpHot {                       // what the verification needs of the parameters
     const KvqParams *cold; GlbBytes tab; GlbWords tab2;
-    int maxerrors, minoverlap;
+    int maxerrors, minoverlap, pitch;
 };
+template <int KK>
 __device__ __forceinline__ void bp_verify_rest(const BpHot &P, GlbBytes text, bool alive, uint32_t roff, int rl, int p, uint32_t kind,
                                                uint32_t en_lo, uint32_t en_hi, int64_t tile_fpos, int stride)
 {
@@ -156,15 +158,15 @@ __device__ __forceinline__ void bp_verify_rest(const BpHot &P, GlbBytes text, bo
                 // [ALL-index read blocks by position] then [ANCHOR blocks by number]
                 bool earlier = false;
                 for (int jj = 0; jj <= me && !earlier; jj++) {
-                    const int ph = jj * SK, pt = rl - (jj + 1) * SK;
-                    if (ph + SK <= rl && (kind == 0u || ph < p)) earlier = seed_live_bp(P.tab2, roff, rl, ph, toff, seql, ph + d);
-                    if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live_bp(P.tab2, roff, rl, pt, toff, seql, pt + d);
+                    const int ph = jj * KK, pt = rl - (jj + 1) * KK;
+                    if (ph + KK <= rl && (kind == 0u || ph < p)) earlier = seed_live_bp<KK>(P.tab2, roff, rl, ph, toff, seql, ph + d);
+                    if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live_bp<KK>(P.tab2, roff, rl, pt, toff, seql, pt + d);
                 }
                 if (kind == 0u) {
                     for (int jj = 0; jj <= me && !earlier; jj++)
                         for (int sft = 0; sft < stride && !earlier; sft++) {
-                            const int o = jj * SK + sft;
-                            if (o < q && ((o - d) & (stride - 1)) == 0) earlier = seed_live_bp(P.tab2, roff, rl, o - d, toff, seql, o);
+                            const int o = jj * P.pitch + sft;
+                            if (o < q && ((o - d) & (stride - 1)) == 0) earlier = seed_live_bp<KK>(P.tab2, roff, rl, o - d, toff, seql, o);
                         }
                 }
                 if (!earlier) { hitAB = canAB; hitC = canC; }
@@ -337,7 +339,9 @@ __device__ __forceinline__ void bp_runs64(uint64_t m, int n, uint32_t dbg, int &
 // own lanes in one pass, worked out per tile.  The launch picks LG = 2 when that is what the records of
 // the text ask for (100 to 250 bases), the general kernel otherwise.
 // DIAG: the kernel honours the KVQ_DBG switches (ablations, forced paths); the production instantiations do not carry them
-template <int SS, int LG, bool STAMPS, bool DIAG = STAMPS>
+// KK: the seed length the table's index was built with (kvq_seed_k: 8 at the product settings, 5 to 7 where (maxerrors + 1) * 8
+// does not fit the shortest accepted overlap)
+template <int SS, int LG, bool STAMPS, bool DIAG = STAMPS, int KK = 8>
 __global__ void __launch_bounds__(ST_THREADS, BP_OCC)
 kvq_scan_bp(const BpArgs *__restrict__ A_)
 {
@@ -357,7 +361,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
         const BpArgsPtr A = bp_args(A_);
         ntiles = A->ntiles; tile_bytes = A->tile_bytes; dbg = DIAG ? A->dbg : 0u; amin = (uint32_t)A->P.amin;
         const GlbWords bm1 = (GlbWords)A->X.bm1;
-        for (int i = tid; i < 2048; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = bm1[i];
+        for (int i = tid; i < (1 << (2 * KK)) / 32; i += ST_THREADS) reinterpret_cast<uint32_t *>(S.bmA)[i] = bm1[i];
     }
     // the drawing wave (the last one, which holds the fewest reads) and its share of the tiles
     uint32_t my_shard = blockIdx.x % BP_SHARDS; bool no_more = false;
@@ -720,13 +724,13 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 {
                     const BpArgsPtr A = bp_args(A_);
                     minrl = A->P.minreadlength; me_ = A->P.maxerrors;
-                    bmL = (const __attribute__((address_space(1))) uint8_t *)A->X.bm1 + 8192;
+                    bmL = (const __attribute__((address_space(1))) uint8_t *)A->X.bm1 + (1 << (2 * KK)) / 8;
                 }
                 const bool mine = have && rl >= minrl && !(dbg & 2u) && grw >= sub && grw - sub < step;       // 1100
                 uint32_t qn = 0;
                 int e0 = 0, e1 = 0;
                 if (mine) {
-                    const int NPe = (rl - SK) / SS + 1;
+                    const int NPe = (rl - KK) / SS + 1;
                     const int per = (NPe + (int)G - 1) >> lg;
                     e0 = (int)mul_u24(gl, (uint32_t)per); if (e0 > NPe) e0 = NPe;
                     e1 = e0 + per; if (e1 > NPe) e1 = NPe;
@@ -735,14 +739,14 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 // (the load is issued whether the block is wanted or not -- any code has its byte in the bitmap --
                 // so that the two lookups of a lane travel together instead of each behind a branch of its own)
                 auto fixed_block = [&](int pp, bool ok) -> bool {
-                    const uint32_t code = cdp_code8(roff + (uint32_t)(ok ? pp : 0));
+                    const uint32_t code = cdp_code<KK>(roff + (uint32_t)(ok ? pp : 0));
                     const uint32_t bits = bmL[code >> 3];
                     return ok & (bool)((bits >> (code & 7u)) & 1u);
                 };
-                auto head_ok = [&](int jj) { return mine && jj <= me_ && (jj + 1) * SK <= rl; };
-                auto tail_ok = [&](int jj) { const int pp = rl - (jj + 1) * SK; return mine && jj <= me_ && pp >= 0 && !((pp % SK) == 0 && pp <= me_ * SK); };
-                const bool hhit = fixed_block((int)gl * SK, head_ok((int)gl));
-                const bool thit = fixed_block(rl - ((int)gl + 1) * SK, tail_ok((int)gl));
+                auto head_ok = [&](int jj) { return mine && jj <= me_ && (jj + 1) * KK <= rl; };
+                auto tail_ok = [&](int jj) { const int pp = rl - (jj + 1) * KK; return mine && jj <= me_ && pp >= 0 && !((pp % KK) == 0 && pp <= me_ * KK); };
+                const bool hhit = fixed_block((int)gl * KK, head_ok((int)gl));
+                const bool thit = fixed_block(rl - ((int)gl + 1) * KK, tail_ok((int)gl));
                 constexpr int NR = SS == 8 ? 6 : SS == 4 ? 12 : (LG == 3 || LG == 1) ? 24 : 18;  // lookups per lane and round (18: a 150-base read's 72 even positions over four lanes; 24: a 300-base read's 147 over eight -- 19 a lane -- or a 100-base read's 47 over two, one round instead of two)
                 bool first = true;
                 for (int ee = e0; __any(ee < e1); ee += NR, first = false) {
@@ -774,7 +778,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                                 const uint32_t word = o <= 16 ? R[wj] : __builtin_amdgcn_alignbit(R[wj + 1 < NW - 1 ? wj + 1 : wj], R[wj], 16);
                                 const uint32_t off = (uint32_t)(o <= 16 ? o : o - 16);
                                 bi[u] = word >> off;                                                        // (its low five bits: the code's)
-                                bb[u] = lds_u32_at(BP_LDS_BMA + ((word >> (off + 3u)) & 0x1FFCu));          // the bitmap word of code >> 5
+                                bb[u] = lds_u32_at(BP_LDS_BMA + ((word >> (off + 3u)) & (((1u << (2 * KK - 3)) - 1u) & ~3u)));          // the bitmap word of code >> 5
                             }
                             asm volatile("" ::: "memory");
 #pragma unroll
@@ -798,8 +802,8 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                             if (idx < BP_QW) q1[idx] = k | ((uint32_t)(SS * (ee + j)) << 9);        // beyond the cap: dropped, the stretch is redone in halves
                             idx++;
                         }
-                        if (hh) { if (idx < BP_QW) q1[idx] = k | ((gl * SK) << 9) | (1u << BP_Q1_KIND); idx++; }
-                        if (th && idx < BP_QW) { const uint32_t pt = (uint32_t)(rl - ((int)gl + 1) * SK); q1[idx] = k | (pt << 9) | (1u << BP_Q1_KIND); }
+                        if (hh) { if (idx < BP_QW) q1[idx] = k | ((gl * KK) << 9) | (1u << BP_Q1_KIND); idx++; }
+                        if (th && idx < BP_QW) { const uint32_t pt = (uint32_t)(rl - ((int)gl + 1) * KK); q1[idx] = k | (pt << 9) | (1u << BP_Q1_KIND); }
                         qn += tot;
                     }
                 }
@@ -808,7 +812,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                     const int jj = t + (int)gl;
 #pragma unroll
                     for (int side = 0; side < 2; side++) {
-                        const int pp = side ? rl - (jj + 1) * SK : jj * SK;
+                        const int pp = side ? rl - (jj + 1) * KK : jj * KK;
                         const bool hit = fixed_block(pp, side ? tail_ok(jj) : head_ok(jj));
                         const uint64_t mm = __ballot(hit);
                         if (mm) {
@@ -859,10 +863,10 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                     BpHot H; GlbWords start; GlbEntries ent; int64_t tile_fpos; int need;
                     {
                         const BpArgsPtr A = bp_args(A_);
-                        H.cold = &A_->P; H.tab = (GlbBytes)A->P.tab; H.tab2 = (GlbWords)A->X.tab2; H.maxerrors = me_; H.minoverlap = A->P.minoverlap;
+                        H.cold = &A_->P; H.tab = (GlbBytes)A->P.tab; H.tab2 = (GlbWords)A->X.tab2; H.maxerrors = me_; H.minoverlap = A->P.minoverlap; H.pitch = A->X.pitch;
                         start = (GlbWords)A->X.start; ent = (GlbEntries)A->X.ent;
                         tile_fpos = A->fpos_base + (int64_t)g0;
-                        need = (me_ + 1) * SK;                            // no alignment is shorter (kvq_seed_index_build)
+                        need = (me_ + 1) * KK;                            // no alignment is shorter (kvq_seed_index_build)
                     }
                     // (the items are numbered in candidate order; the queue takes BP_Q2W of them a round -- one round, unless a read matches
                     // dozens of sequences of a dense table: then the candidates, a hundred at most, are simply walked again for the next window)
@@ -873,8 +877,8 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                             uint32_t en0 = 0, ne = 0;
                             if (qi < qn_ok) {
                                 const uint32_t cd = q1[qi];
-                                const uint32_t code = cdp_code8((S.rinfo[cd & 511u] & 0xFFFFu) + ((cd >> 9) & 0xFFFFu));
-                                const u32x2_t st = *(GlbPairs)(start + (code | ((cd >> BP_Q1_KIND) << 16)));      // (the ALL index's codes follow the anchors')
+                                const uint32_t code = cdp_code<KK>((S.rinfo[cd & 511u] & 0xFFFFu) + ((cd >> 9) & 0xFFFFu));
+                                const u32x2_t st = *(GlbPairs)(start + (code | ((cd >> BP_Q1_KIND) << (2 * KK))));      // (the ALL index's codes follow the anchors')
                                 en0 = st.x; ne = st.y - st.x;
                             }
                             const uint32_t inc = kvq_wave_incl_scan(ne);
@@ -913,7 +917,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                                     alive = __popc(dm) <= me_;
                                 }
                             }
-                            if (__any(alive)) bp_verify_rest(H, text, alive, croff, crl, p, kind, en_lo, en_hi, tile_fpos, SS);
+                            if (__any(alive)) bp_verify_rest<KK>(H, text, alive, croff, crl, p, kind, en_lo, en_hi, tile_fpos, SS);
                         }
                         if (run <= w0 + BP_Q2W) break;
                     }

@@ -20,7 +20,7 @@
 #else
 #define KVQ_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #endif
-#define SK 8                       // seed length
+#define KVQ_K_MAX 8                // the longest seed (16 code bits; an 8 KiB bitmap of the anchors in LDS); the shortest is 5
 #define ST_TILE 36640u             // bytes a tile owns at the full look-ahead: 458 scan blocks of 80 bytes (tile + look-ahead = 510 blocks)
 #define ST_TILE_MIN 30960u         // the least a tile owns (kvq_choose_tile cuts a tile to a whole number of lane groups)
 #define ST_OV 4160u                // look-ahead for the tile's last record (52 blocks)
@@ -58,10 +58,13 @@ struct SeedTables {
     const SeedEntry *ent;                     // the entries of both indexes, the anchors' first
     const uint32_t *tab2;                     // the sequence table as 2-bit codes, 16 bases per word (kernels_bp.hip)
     int32_t stride;                           // read positions 0, stride, 2*stride, ... are looked up for anchors (2, 4 or 8)
+    int32_t pitch;                            // a sequence's anchor blocks start at offsets pitch j + sft, sft < stride
 };
 
 struct SeedIndex {
-    int stride = 2;           // anchor blocks sit at sequence offsets 8j + 0 .. 8j + stride - 1
+    int stride = 2;           // anchor blocks sit at sequence offsets K j + 0 .. K j + stride - 1
+    int k = 8;                // seed length
+    int pitch = 8;            // distance of a sequence's anchor blocks: K rounded up to a multiple of the stride
     DevBuf d_bm1, d_start, d_ent, d_tab2;
     SeedTables dev;
 };
@@ -69,11 +72,28 @@ struct SeedIndex {
 __host__ __device__ static inline uint32_t code2_of(uint8_t c) { return (c >> 1) & 3u; }
 
 // 16-bit seed code of 8 bases: base t in bits 2t..2t+1 (rolls along a read with one shift)
-static uint32_t host_code8(const uint8_t *p)
+static uint32_t host_code(const uint8_t *p, int K)
 {
     uint32_t c = 0;
-    for (int i = 0; i < SK; i++) c |= code2_of(p[i]) << (2 * i);
+    for (int i = 0; i < K; i++) c |= code2_of(p[i]) << (2 * i);
     return c;
+}
+
+// The seed length for a configuration: every accepted alignment is at least min(minoverlap, minreadlength) long (class A/B
+// overlaps are >= minoverlap, class C lengths are min(readlength, sequence length), and a seeded sequence is longer than
+// that), so with maxerrors + 1 disjoint blocks of K <= that / (maxerrors + 1) bases one block is free of errors.  8 where it
+// fits (test_engine.py:208-224 sweeps maxerrors 0..3 at minoverlap 25: K = 8, 8, 8, 6; test_analyser.py:55-58 has
+// minoverlap 10, maxerrors 1: K = 5); below 5 the bitmaps say nothing and the exhaustive kernels serve the table.
+// KVQ_K = 5..8 caps it (tests).  0: no seed filter.
+int kvq_seed_k(const kvq_config &cfg)
+{
+    const int e = cfg.maxerrors;
+    if (e < 0 || e > 6) return 0;
+    if (cfg.Amin <= 13) return 0;                // the kernel relies on '\n' and '\r' closing every quality run (1058)
+    int K = std::min(cfg.minoverlap, cfg.minreadlength) / (e + 1);
+    if (K > KVQ_K_MAX) K = KVQ_K_MAX;
+    if (const char *kv = getenv("KVQ_K")) { const int w = atoi(kv); if (w >= 5 && w < K) K = w; }
+    return K >= 5 ? K : 0;
 }
 
 SeedIndex *kvq_seed_index_build(kvq_table *t)
@@ -81,16 +101,19 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     const kvq_config &cfg = t->cfg;
     t->seed_k = 0;
     const int e = cfg.maxerrors;
-    if (e < 0 || e > 6) return nullptr;
-    const int need = (e + 1) * SK;
-    // every accepted alignment must be at least `need` long: class A/B overlaps
-    // are >= minoverlap, class C lengths are min(readlength, sequence length)
-    if (cfg.minoverlap < need || cfg.minreadlength < need) return nullptr;
-    if (cfg.Amin <= 13) return nullptr;          // the kernel relies on '\n' and '\r' closing every quality run (1058)
+    const int K = kvq_seed_k(cfg);
+    if (!K) return nullptr;
+    // The anchor blocks of a sequence: e + 1 blocks of K bases, `pitch` apart, in `stride` shifted copies (offsets pitch j + sft, sft < stride).
+    // A sequence that lies in a read at offset d is met through the copy with sft = -d mod stride, at read positions that are multiples of the
+    // stride -- for that, all blocks of a copy must sit in ONE residue class, so the pitch is K rounded up to a multiple of the stride (8 for
+    // K = 8; a pitch of K = 5 with stride 4 would need block 1 of another copy, which overlaps block 0: one error could break both).  The
+    // copies must fit the sequence: length >= pitch e + K + stride - 1.
+    auto pitch_of = [&](int stride) { return (K + stride - 1) / stride * stride; };
+    auto span_of = [&](int stride) { return pitch_of(stride) * e + K + stride - 1; };
     int minlen = 1 << 30;
     for (int s = 0; s < t->nseq; s++) {
         const int len = t->h_off[s + 1] - t->h_off[s];
-        bool ok = len >= need + 1 && len <= 4095 && t->h_off[s] < (1 << 20) && s < (1 << 20);   // the shifted anchor sets need stride - 1 more bases
+        bool ok = len >= span_of(2) && len <= 4095 && t->h_off[s] < (1 << 20) && s < (1 << 20);   // (stride 2 at least)
         for (int i = 0; ok && i < len; i++) {
             const uint8_t c = t->h_tab[t->h_off[s] + i];
             ok = (c == 'A' || c == 'C' || c == 'G' || c == 'T');
@@ -98,15 +121,13 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
         if (ok) { t->seeded.push_back(s); t->is_seeded[s] = 1; minlen = std::min(minlen, len); }
     }
     if (t->seeded.empty()) return nullptr;
-    t->seed_k = SK;
-    // a sequence contained in a read at offset d is met through the anchor block at sequence
-    // offset 8j + sft with sft = -d mod stride, at a read position that is a multiple of the
-    // stride: the wider the stride the fewer lookups per read (and the more index entries per
-    // sequence -- the expected number of candidates stays the same).  Every seeded sequence
-    // must be able to hold its shifted blocks: length >= 8(e+1) + stride - 1.
-    int stride = minlen >= need + 7 ? 8 : minlen >= need + 3 ? 4 : 2;
+    t->seed_k = K;
+    // the wider the stride the fewer lookups per read (and the more index entries per sequence -- the expected number of
+    // candidates stays the same): the widest one whose copies every seeded sequence can hold
+    int stride = minlen >= span_of(8) ? 8 : minlen >= span_of(4) ? 4 : 2;
     if (const char *sv = getenv("KVQ_STRIDE")) { const int w = atoi(sv); if ((w == 2 || w == 4 || w == 8) && w <= stride) stride = w; }
 
+    const int pitch = pitch_of(stride);
     struct Ent { uint32_t key; SeedEntry e; };                  // key = code, + 65536 for the index of all positions
     std::vector<Ent> v;
     for (int s : t->seeded) {
@@ -116,11 +137,11 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
         auto entry = [&](int pos, uint32_t all) -> Ent {
             uint64_t ctx = 0;
             for (int i = 0; i < 32; i++) { const int sp = pos - 16 + i; if (sp >= 0 && sp < len) ctx |= (uint64_t)code2_of(q[sp]) << (2 * i); }
-            return Ent{ host_code8(q + pos) + (all << 16), SeedEntry{ hi | (uint64_t)pos, ctx } };
+            return Ent{ host_code(q + pos, K) + (all << (2 * K)), SeedEntry{ hi | (uint64_t)pos, ctx } };
         };
         for (int j = 0; j <= e; j++)
-            for (int sft = 0; sft < stride; sft++) v.push_back(entry(j * SK + sft, 0u));
-        for (int p = 0; p + SK <= len; p++) v.push_back(entry(p, 1u));
+            for (int sft = 0; sft < stride; sft++) v.push_back(entry(j * pitch + sft, 0u));
+        for (int p = 0; p + K <= len; p++) v.push_back(entry(p, 1u));
     }
     if (v.size() >= (1u << 22)) {
         // (a work item of the scan kernel names its entry with 22 bits: a table this large goes to the exhaustive kernels as a whole)
@@ -128,20 +149,21 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
         return nullptr;
     }
     SeedIndex *ix = new SeedIndex();
-    ix->stride = stride;
-    std::vector<uint8_t> bm1(16384, 0);
+    ix->stride = stride; ix->k = K; ix->pitch = pitch;
+    const uint32_t NC = 1u << (2 * K);                          // codes
+    std::vector<uint8_t> bm1(2 * NC / 8 < 64 ? 64 : 2 * NC / 8, 0);          // the anchors' bitmap, then the one of all positions
     std::stable_sort(v.begin(), v.end(), [](const Ent &a, const Ent &b) { return a.key < b.key; });
-    std::vector<uint32_t> start(131073 + 1, 0); std::vector<SeedEntry> ent(v.size() + 1, SeedEntry{ 0, 0 });
+    std::vector<uint32_t> start(2 * (size_t)NC + 2, 0); std::vector<SeedEntry> ent(v.size() + 1, SeedEntry{ 0, 0 });
     for (size_t i = 0; i < v.size(); i++) {
-        bm1[v[i].key >> 3] |= (uint8_t)(1u << (v[i].key & 7));                  // (bit 16 of the key = the second bitmap)
+        bm1[v[i].key >> 3] |= (uint8_t)(1u << (v[i].key & 7));                  // (bit 2K of the key = the second bitmap)
         start[v[i].key + 1]++; ent[i] = v[i].e;
     }
-    for (int c = 0; c < 131072; c++) start[c + 1] += start[c];
-    start[131073] = start[131072];
+    for (uint32_t c = 0; c < 2 * NC; c++) start[c + 1] += start[c];
+    start[2 * (size_t)NC + 1] = start[2 * (size_t)NC];
     if (ix->d_start.ensure(start.size() * 4) != KVQ_OK || ix->d_ent.ensure(ent.size() * sizeof(SeedEntry)) != KVQ_OK ||
         hipMemcpy(ix->d_start.p, start.data(), start.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ix->d_ent.p, ent.data(), ent.size() * sizeof(SeedEntry), hipMemcpyHostToDevice) != hipSuccess ||
-        ix->d_bm1.ensure(16384) != KVQ_OK || hipMemcpy(ix->d_bm1.p, bm1.data(), 16384, hipMemcpyHostToDevice) != hipSuccess) {
+        ix->d_bm1.ensure(bm1.size()) != KVQ_OK || hipMemcpy(ix->d_bm1.p, bm1.data(), bm1.size(), hipMemcpyHostToDevice) != hipSuccess) {
         if (!kvq_error_code()) kvq_set_error(KVQ_ERR_DEVICE, "uploading the seed index failed");
         kvq_seed_index_destroy(ix);
         return nullptr;
@@ -160,7 +182,7 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
         ix->dev.tab2 = ix->d_tab2.as<uint32_t>();
     }
     ix->dev.start = ix->d_start.as<uint32_t>(); ix->dev.ent = ix->d_ent.as<SeedEntry>();
-    ix->dev.stride = stride;
+    ix->dev.stride = stride; ix->dev.pitch = pitch;
     return ix;
 }
 

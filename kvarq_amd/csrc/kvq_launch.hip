@@ -122,8 +122,17 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         }
         if (lg_env >= -1) lg = lg_env >= 1 && lg_env <= 3 ? lg_env : -1;
         if ((lg == 3 || lg == 1) && st) lg = -1;                                // (no instrumented build of those)
-        if ((dbg & ~16u) && !st && lg != 2) lg = -1;
-        const BpKernel kern = ((dbg & ~16u) && !st) ? kernels_diag[(lg == 2 ? 3 : 0) + si] : kernels_bp[lg == 3 ? 12 + si : lg == 1 ? 15 + si : (lg == 2 ? 6 : 0) + si + st];
+        // (seeds shorter than 8 -- (maxerrors + 1) * 8 above the shortest accepted overlap: kvq_seed_k -- have the general and the four-lane kernel)
+        static const BpKernel kernels_k5[6] = { kvq_scan_bp<2, -1, false, true, 5>, kvq_scan_bp<4, -1, false, true, 5>, kvq_scan_bp<8, -1, false, true, 5>,
+                                                kvq_scan_bp<2, 2, false, true, 5>, kvq_scan_bp<4, 2, false, true, 5>, kvq_scan_bp<8, 2, false, true, 5> };
+        static const BpKernel kernels_k6[6] = { kvq_scan_bp<2, -1, false, true, 6>, kvq_scan_bp<4, -1, false, true, 6>, kvq_scan_bp<8, -1, false, true, 6>,
+                                                kvq_scan_bp<2, 2, false, true, 6>, kvq_scan_bp<4, 2, false, true, 6>, kvq_scan_bp<8, 2, false, true, 6> };
+        static const BpKernel kernels_k7[6] = { kvq_scan_bp<2, -1, false, true, 7>, kvq_scan_bp<4, -1, false, true, 7>, kvq_scan_bp<8, -1, false, true, 7>,
+                                                kvq_scan_bp<2, 2, false, true, 7>, kvq_scan_bp<4, 2, false, true, 7>, kvq_scan_bp<8, 2, false, true, 7> };
+        const bool diag = ((dbg & ~16u) && !st) || ix->k != 8;
+        if (diag && lg != 2) lg = -1;
+        const BpKernel *const dk = ix->k == 5 ? kernels_k5 : ix->k == 6 ? kernels_k6 : ix->k == 7 ? kernels_k7 : kernels_diag;
+        const BpKernel kern = diag ? dk[(lg == 2 ? 3 : 0) + si] : kernels_bp[lg == 3 ? 12 + si : lg == 1 ? 15 + si : (lg == 2 ? 6 : 0) + si + st];
         hipLaunchKernelGGL(kern, dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
     }
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));

@@ -424,7 +424,14 @@ def test_seeded_and_exhaustive_kernels_agree_and_paths_are_as_expected(tmp_path)
         'long_reads': dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False),     # 11 kB in all: one tile holds it
         'ragged_crlf': dict(seeded=False, exhaustive=True, rescanned=False, tiles_rescanned=False),    # e=3, minoverlap 12: not seedable
         'findseqs': dict(seeded=False, exhaustive=True, rescanned=False, tiles_rescanned=False),
+        # seeds shorter than 8 where (maxerrors + 1) * 8 does not fit the shortest accepted overlap (kvq_seed_k): the reference's own
+        # maxerrors sweep at minoverlap 25 (test_engine.py:208-224: e = 3 -> K = 6) and its analyser settings (test_analyser.py:55-58:
+        # minoverlap 10, maxerrors 1 -> K = 5) stay on the seed filter
+        'maxerror3': dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False),
+        'maxerror2': dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False),
+        'spoligo_analyser': dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False),
     }
+    want_k = {'maxerror3': 6, 'maxerror2': 8, 'spoligo_analyser': 5, 'synth20k_mtbc': 8}
     # a 9 kB record that starts 36 kB into the text outgrows the look-ahead of the tile that owns it
     # (a tile and its look-ahead span 40.8 kB): that tile's records are scanned again by the exhaustive kernels
     import os
@@ -445,6 +452,8 @@ def test_seeded_and_exhaustive_kernels_agree_and_paths_are_as_expected(tmp_path)
             text = filler + cases.rec('big', big, 'I' * 4400) + text
         data = np.frombuffer(text, dtype=np.uint8)
         t = scan.Table(case.seq_bytes(), **case.config)
+        if name in want_k and not os.environ.get('KVQ_K'):
+            assert t.seed_k == want_k[name], (name, t.seed_k)
         res = []
         for force in (False, True):
             s = scan.Scanner(t)
@@ -889,7 +898,8 @@ def test_reads_longer_than_4095_bases_keep_their_late_candidates(tmp_path):
     d = scan.DeviceBuffer(arr.nbytes); d.upload(arr)
     s.scan_device(d.ptr, arr.nbytes, scan.chunk_offsets(arr))
     q = s.finish()
-    assert q['path'] == dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False), q['path']
+    if os.environ.get('KVQ_K', '8') in ('', '0', '6', '7', '8'):   # (a 5-mer filter lets a 9 000-base read flood its wave's queue: that read goes through the redo, by design)
+        assert q['path'] == dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False), q['path']
     assert tuple(q['hits']) == tuple(o['hits'])
     s.close(); t.close(); d.free()
 
