@@ -229,7 +229,19 @@ int kvq_comm_max_status(kvq_comm *c, unsigned long long mine, unsigned long long
     return KVQ_OK;
 }
 
-extern "C" int32_t kvq_scan_set_comm(kvq_scan *s, kvq_comm *c) { s->comm = c; return KVQ_OK; }
+// (what the collective finish needs on the device is allocated HERE, where a failure is this rank's own affair: a rank that
+// could not allocate inside `finish` would leave the others waiting in a collective it never enters)
+extern "C" int32_t kvq_scan_set_comm(kvq_scan *s, kvq_comm *c)
+{
+    kvq_clear_error();
+    if (c) {
+        int rc;
+        if ((rc = s->d_finish.ensure(sizeof(KvqFinishState) + 256))) return rc;
+        if ((rc = s->d_ctr_all.ensure((size_t)s->t->ctr_len * 8))) return rc;
+    }
+    s->comm = c;
+    return KVQ_OK;
+}
 
 // a free-standing form for callers that hold the counters of several scans in one device array of their own
 extern "C" int32_t kvq_comm_allreduce_counters(kvq_comm *c, void *d_counters, int64_t ctr_len, void *d_scratch16)

@@ -703,24 +703,45 @@ static int stream_batches(Sink &sink, const char *const *files, int nfiles, uint
 
 // the GPU sink: one kvq_scan_host per batch, live stats after each
 struct ScanSink {
-    kvq_scan *s; std::vector<int64_t> ctr_live; bool have_live = false; int64_t live_parsed = 0;
-    void begin(int64_t total) { live_reset(s->t->nseq, total); ctr_live.resize((size_t)s->t->ctr_len); }
+    kvq_scan *s = nullptr;
+    // The live statistics (engine.stats() from another thread while findseqs runs: workhorse.c:1205-1244 reads the workers' counters
+    // under their lock) are ONE consistent snapshot: the head of the counter array copied on the scan's own stream, behind the kernels
+    // of the batches enqueued so far and in front of the next one's, into pinned memory -- published by the next call together with
+    // the byte count that belongs to it.  (Round 3 copied on the null stream, beside the non-blocking stream's kernels: records, read
+    // lengths and hits per sequence of different batches in one answer.)
+    int64_t *snap = nullptr; size_t snap_cap = 0, head = 0; hipEvent_t snap_ev = nullptr;
+    bool snap_pending = false; int64_t snap_parsed = 0, enq_parsed = 0, last_parsed = 0;
+    ~ScanSink() { if (snap_ev) (void)hipEventDestroy(snap_ev); if (snap) pinned_give(snap, snap_cap); }
+    void begin(int64_t total)
+    {
+        live_reset(s->t->nseq, total);
+        // (only the head of the counter array -- scalars, read lengths, hits per sequence: 12 KB for the MTBC table -- not the
+        // coverage and mutation counters behind it, 0.8 MB)
+        head = std::min((size_t)std::max<int64_t>(s->t->off_nseqbasehits + s->t->nseq, KVQ_CTR_READLENGTHS + KVQ_MAX_READLENGTH), (size_t)s->t->ctr_len);
+        if (!snap) snap = (int64_t *)pinned_take(head * 8, &snap_cap);
+        if (!snap_ev) (void)hipEventCreateWithFlags(&snap_ev, hipEventDisableTiming);
+        snap_pending = false; enq_parsed = last_parsed = 0;
+    }
     int batch(const uint8_t *data, int64_t nbytes, const int64_t *off, int64_t nchunks, int64_t fpos, int64_t parsed, int64_t total)
     {
-        // publish the counters so far (engine.stats() may be polling), hand this batch over (its text sets out at once, the
-        // kernels of the batch before it are enqueued: kvq_scan_host_async) and return, so that the reader fills the other
-        // host buffer while this one crosses PCIe
-        // (only the head of the counter array -- scalars, read lengths, hits per sequence: 12 KB for the MTBC table -- not the
-        // coverage and mutation counters behind it, 0.8 MB: the blocking copy of all of it cost 5 % of a 3 GB file)
-        if (have_live) {
-            const size_t head = (size_t)std::max<int64_t>(s->t->off_nseqbasehits + s->t->nseq, KVQ_CTR_READLENGTHS + KVQ_MAX_READLENGTH);
-            if (hipMemcpy(ctr_live.data(), s->d_ctr, std::min(head, (size_t)s->t->ctr_len) * 8, hipMemcpyDeviceToHost) != hipSuccess) {
-                kvq_set_error(KVQ_ERR_DEVICE, "device failure during scan"); return KVQ_ERR_DEVICE;
-            }
-            live_from_counters(s->t, ctr_live.data(), live_parsed, total);
+        // publish the snapshot taken behind the batches that were enqueued two calls ago (it landed while this batch was read)
+        if (snap_pending) {
+            if (hipEventSynchronize(snap_ev) != hipSuccess) { kvq_set_error(KVQ_ERR_DEVICE, "device failure during scan"); return KVQ_ERR_DEVICE; }
+            live_from_counters(s->t, snap, snap_parsed, total);            // (it reads the head only)
+            snap_pending = false;
         }
-        have_live = true; live_parsed = parsed;
-        return kvq_scan_host_async(s, data, nbytes, off, nchunks, fpos);
+        // hand this batch over (its text sets out at once, the kernels of the batch before it are enqueued: kvq_scan_host_async) and
+        // return, so that the reader fills the other host buffer while this one crosses PCIe
+        const int rc = kvq_scan_host_async(s, data, nbytes, off, nchunks, fpos);
+        if (rc) return rc;
+        // the stream now holds the kernels of every batch up to the one handed over in the call before this: snapshot behind them
+        if (snap && snap_ev && last_parsed > 0) {
+            if (hipMemcpyAsync(snap, s->d_ctr, head * 8, hipMemcpyDeviceToHost, s->stream) == hipSuccess && hipEventRecord(snap_ev, s->stream) == hipSuccess) {
+                snap_pending = true; snap_parsed = last_parsed;
+            } else (void)hipGetLastError();
+        }
+        last_parsed = parsed;
+        return KVQ_OK;
     }
 };
 

@@ -51,6 +51,7 @@ struct kvq_table {
     std::vector<int32_t> seeded;         // sequences the seed-filter kernel serves
     std::vector<uint8_t> is_seeded;
     int32_t seed_k = 0;
+    int device = 0;                      // the device the table's blocks live on
     DevBuf d_tab, d_off, d_exh, d_all, d_seeded;
     struct SeedIndex *index = nullptr;   // kernels_seeded
     int64_t ctr_len, off_nseqhits, off_nseqbasehits, off_cov, off_mut;
@@ -126,7 +127,7 @@ struct kvq_scan {
     std::vector<Batch> batches;
     bool host_batches = false;
     int64_t host_pending = -1;           // index of the host batch in flight (kvq_scan_host_async), -1: none
-    hipEvent_t ev_chain = nullptr;       // this scan's last seed-filter launch is through, kvq_validate_tiles included (what the next scan of the process waits for)
+    hipEvent_t ev_chain = nullptr;       // this scan's last seed-filter launch is through (recorded right behind the scan kernel, in front of kvq_validate_tiles: what the next scan of the process waits for)
     int64_t records = 0;
     int64_t parsed = 0, total = 0;
     // timing

@@ -28,6 +28,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         const uint32_t a = (uint32_t)co[c], b = (uint32_t)co[c + 1];
         nt += b > a ? (uint32_t)(((uint64_t)b - (a & ~15u) + TILE - 1) / TILE) : 0u;
     }
+    s->cur_ntiles = 0;                  // (run_batch leaves the redo chain out behind a launch that scanned no tile: its counts are only zeroed by kvq_expand_tiles)
     if (nt == 0) {                      // (nothing to scan: the pair of events of the batch is recorded all the same)
         if (!s->ev_main.empty()) { KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream)); KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream)); }
         return KVQ_OK;

@@ -73,7 +73,12 @@ struct BlockCache {
     }
     bool put(void *p, size_t cap)
     {
+        // the device that OWNS the block, not the one that is current in the calling thread: a scan may be destroyed from
+        // another thread than the one that made it (Python's garbage collector; ranks as threads closed by their parent),
+        // and a block filed under the wrong device would later be handed to a scan there
         int dev = 0; (void)hipGetDevice(&dev);
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device; else (void)hipGetLastError();
         std::lock_guard<std::mutex> l(m);
         if (cap > max_bytes / 2 || v.size() >= 256) return false;
         while (bytes + cap > max_bytes && !v.empty()) {          // the oldest blocks make room
@@ -83,6 +88,7 @@ struct BlockCache {
         v.push_back({ p, cap, dev }); bytes += cap;
         return true;
     }
+    size_t held() { std::lock_guard<std::mutex> l(m); return bytes; }
     void drop()
     {
         std::lock_guard<std::mutex> l(m);
@@ -105,7 +111,7 @@ int DevBuf::ensure(size_t n)
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     if (cache_on()) { size_t c = 0; if (void *q = g_dev_blocks.take(n + 256, &c)) { p = q; cap = c; return KVQ_OK; } }
     hipError_t e = hipMalloc(&p, want);
-    if (e == hipErrorOutOfMemory && g_dev_blocks.bytes) { g_dev_blocks.drop(); e = hipMalloc(&p, want); }
+    if (e == hipErrorOutOfMemory && g_dev_blocks.held()) { g_dev_blocks.drop(); e = hipMalloc(&p, want); }
     if (e != hipSuccess) {
         p = nullptr;
         kvq_set_error(e == hipErrorOutOfMemory ? KVQ_ERR_MEMORY : KVQ_ERR_DEVICE, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
@@ -203,6 +209,7 @@ extern "C" kvq_table *kvq_table_create(const uint8_t *const *seqs, const int32_t
     t->off_mut = t->off_cov + tot;
     t->ctr_len = t->off_mut + 6 * tot;
 
+    (void)hipGetDevice(&t->device);
     t->is_seeded.assign((size_t)nseq, 0);
     t->index = kvq_seed_index_build(t);      // fills seeded / is_seeded / seed_k
     if (kvq_error_code()) { kvq_table_destroy(t); return nullptr; }
@@ -228,7 +235,14 @@ extern "C" kvq_table *kvq_table_create(const uint8_t *const *seqs, const int32_t
 extern "C" void kvq_table_destroy(kvq_table *t)
 {
     if (!t) return;
-    (void)hipDeviceSynchronize();      // (its blocks go to the cache, not through hipFree: nothing may still be reading them)
+    {
+        // (its blocks go to the cache, not through hipFree: nothing may still be reading them -- on the device the table lives on,
+        // which need not be the calling thread's current one)
+        int cur = 0; (void)hipGetDevice(&cur);
+        if (t->device != cur) (void)hipSetDevice(t->device);
+        (void)hipDeviceSynchronize();
+        if (t->device != cur) (void)hipSetDevice(cur);
+    }
     if (t->index) kvq_seed_index_destroy(t->index);
     t->d_tab.release(); t->d_off.release(); t->d_exh.release(); t->d_all.release(); t->d_seeded.release();
     delete t;
@@ -366,6 +380,7 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     s->d_stage_ctr = (unsigned long long *)((char *)s->d_small.p + SMALL_STAGE);
     if (ensure_arena(s, 1u << 20, 64ull << 20) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     if (s->d_redo.ensure(KvqRedo::bytes()) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
+    if (hipMemsetAsync(s->d_redo.p, 0, 256, s->stream) != hipSuccess) { kvq_scan_destroy(s); return nullptr; }      // (the block comes from the cache as it was left: the redo's two counts start at zero)
     s->pin_cap = (size_t)t->ctr_len * 8 + (4u << 20);
     {
         const size_t small_b = 64 + 4 * (size_t)KVQ_MAX_BATCHES + 512;
@@ -608,7 +623,7 @@ static int run_batch(kvq_scan *s, const uint8_t *d_data, int64_t nbytes, const i
     // empty launches).  A batch that failed validation is left alone (it is redone as a whole), and so is one whose
     // skipped tiles hold more records than KVQ_REDO_CAP (kvq_dev_count raises its fail bit).  Their hits lie in the
     // batch's own range of the arena, closed below.
-    if (use_seeded) {
+    if (use_seeded && s->cur_ntiles) {         // (a batch of empty chunks has scanned no tile: nothing was skipped, and the redo's counts are the LAST launch's)
         const KvqRedo Rd(s->d_redo.p);
         unsigned int *const failw = s->d_fail + batch_no;
         const KvqSkippedTile *tiles = reinterpret_cast<const KvqSkippedTile *>(s->pool.d + s->cur_skip_at);
@@ -942,6 +957,7 @@ int kvq_scan_finish_internal(kvq_scan *s)
 static int finish_over_ranks(kvq_scan *s, int rc_own)
 {
     int rc;
+    // (d_finish and d_ctr_all were made by kvq_scan_set_comm: nothing in front of the status exchange can fail on this rank alone)
     if ((rc = s->d_finish.ensure(sizeof(KvqFinishState) + 256))) return rc;
     unsigned long long *scratch = (unsigned long long *)((char *)s->d_finish.p + ((sizeof(KvqFinishState) + 15) & ~(size_t)15));
     unsigned long long worst = 0;

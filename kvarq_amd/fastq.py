@@ -1,54 +1,44 @@
-"""``kvarq.fastq`` counterpart, as far as the engine needs it: the exception the
-scan raises on malformed records (reference kvarq/fastq.py; resolved by the C
-engine at import, csrc/workhorse.c:1598-1600) and the PHRED -> ASCII helper the
-callers use to derive ``Amin`` (kvarq/fastq.py:41-42, 245-247)."""
+"""``kvarq.fastq`` for the MI355X engine: the exception the scan raises on malformed records, the PHRED
+scale helpers callers derive ``Amin`` from, and ``Fastq`` -- the cheap look at a ``.fastq`` / ``.fastq.gz``
+file that callers take before a scan (PHRED offset, read length, record estimate, the second file of a pair)
+and after it (the record or the bases a hit came from).
 
+The attribute and method names are the reference module's (kvarq/fastq.py:38-387: ``Analyser``, the CLI and the
+tests reach for them); the implementation is this repository's own, built from three small parts:
 
-class FastqFileFormatException(Exception):
-    """raised when a record does not start with '@' or its 3rd line not with '+'"""
+* :class:`PhredScale` -- which vendor scales hold a range of score characters (pure arithmetic on a table);
+* :func:`survey` -- ONE pass over a sample of records that validates each record and collects everything the
+  constructor wants to know (score range, first read length, first record size);
+* :class:`_Backtrack` -- finds the record around a file position from a block of bytes read backwards, in memory.
 
-
-# quality characters in ASCII order, as kvarq/fastq.py:41-42 lists them
-ASCII = ''.join(chr(c) for c in range(33, 127))
-
-# vendor variants: name -> dQ (offset of Q=0 inside ASCII), kvarq/fastq.py:44-53
-VARIANTS = {'Sanger': 0, 'Solexa': 31, 'Illumina 1.3+': 31, 'Illumina 1.5+': 31, 'Illumina 1.8+': 0}
-
-
-def Q2A(Q, variant='Sanger'):
-    """ASCII character of PHRED score ``Q`` (kvarq/fastq.py:245-247); Q=13 on
-    Sanger/Illumina 1.8+ is '.', the product default ``Amin`` (kvarq/config.py:3)"""
-    return ASCII[Q + VARIANTS[variant]]
-
-
-# --- the probe -----------------------------------------------------------------
-
+The scan itself never goes through this module (engine.findseqs reads the files in C++).
+"""
 import collections
 import gzip
+import itertools
 import math
 import os
 
 from .log import lo
 
+
+class FastqFileFormatException(Exception):
+    """raised when a record does not start with '@' or its 3rd line not with '+' (csrc/workhorse.c:1037-1048
+    resolves this class at import, 1598-1600), and by :class:`Fastq` for files it cannot make sense of"""
+
+
+# --- PHRED scales ----------------------------------------------------------------------------------------
+
+ASCII = ''.join(map(chr, range(33, 127)))          # the score characters, '!' first (kvarq/fastq.py:41-42)
+
 VendorProperties = collections.namedtuple('VendorProperties', ['Qrange', 'dQ'])
 
 
-class Fastq(object):
-    """
-    ``kvarq.fastq.Fastq`` for Python 3 (reference kvarq/fastq.py:38-387): opens a ``.fastq`` /
-    ``.fastq.gz`` file, checks the format of a sample of records, derives the PHRED offset
-    (``dQ``, ``Azero``) from the score characters it sees, estimates read length and record
-    count and finds the second file of a ``_1`` / ``_2`` pair.  The scan itself never goes
-    through this class; callers use it to pick ``Amin`` (``Q2A``) and the file list
-    (``filenames``) for ``engine.findseqs`` (kvarq/analyse.py:336-358, kvarq/cli.py:73-85).
+class PhredScale(object):
+    """the vendor scales: name -> (scores a file of that vendor may hold, offset of Q = 0 in ``ASCII``);
+    data of kvarq/fastq.py:47-53, in its order (the order of ``Fastq.variants``)"""
 
-    Text is handled as latin-1 ``str`` throughout (one character per byte).
-    """
-
-    ASCII = ASCII
-
-    # declaration order decides the order of ``.variants`` (kvarq/fastq.py:47-53)
-    vendor_variants = collections.OrderedDict((
+    TABLE = collections.OrderedDict((
         ('Sanger', VendorProperties(range(0, 50), 0)),
         ('Solexa', VendorProperties(range(-5, 41), 31)),
         ('Illumina 1.3+', VendorProperties(range(0, 41), 31)),
@@ -56,170 +46,259 @@ class Fastq(object):
         ('Illumina 1.8+', VendorProperties(range(0, 62), 0)),
     ))
 
+    @classmethod
+    def holding(cls, lowest, highest):
+        """names of the scales whose score range holds both ASCII indices"""
+        return [name for name, v in cls.TABLE.items() if lowest - v.dQ in v.Qrange and highest - v.dQ in v.Qrange]
+
+    @classmethod
+    def offset(cls, name):
+        return cls.TABLE[name].dQ
+
+
+VARIANTS = {name: v.dQ for name, v in PhredScale.TABLE.items()}
+
+
+def Q2A(Q, variant='Sanger'):
+    """ASCII character of PHRED score ``Q``; Q = 13 on Sanger / Illumina 1.8+ is '.', the product's default
+    ``Amin`` (kvarq/fastq.py:245-247, kvarq/config.py:3)"""
+    return ASCII[Q + PhredScale.offset(variant)]
+
+
+# --- one pass over a sample of records -------------------------------------------------------------------
+
+Record = collections.namedtuple('Record', ['identifier', 'bases', 'separator', 'scores'])
+Survey = collections.namedtuple('Survey', ['records', 'lowest', 'highest', 'first'])
+
+_BASES = frozenset('ACGTN')
+_SCORES = frozenset(ASCII)
+
+
+def check_record(rec):
+    """the four format rules of a record (what kvarq/fastq.py:196-222 checks); raises FastqFileFormatException"""
+    if not rec.identifier.startswith('@'):
+        raise FastqFileFormatException('identifier (1st line of record) must begin with "@"')
+    if not _BASES.issuperset(rec.bases):
+        raise FastqFileFormatException('bases (2nd line of record) must contain only AGCTN')
+    if rec.separator != '+' and rec.separator != '+' + rec.identifier[1:]:
+        raise FastqFileFormatException('separator (3rd line of record) must be == "+" or "+(ident)"')
+    extra = len(rec.scores) - len(rec.bases)
+    if not (extra == 0 or (extra == 1 and rec.scores.endswith('!'))):
+        raise FastqFileFormatException('bases must be ~ same length as phred score (2nd, 4th line)')
+    if not _SCORES.issuperset(rec.scores):
+        raise FastqFileFormatException('phred score (4th line of record) must contain only "%s"' % ASCII)
+
+
+def _quota(n, points):
+    """how many of ``n`` sample records each of ``points`` places of a file gets (the remainder goes to the last places)"""
+    return [(k + 1) * n // points - k * n // points for k in range(points)]
+
+
+def survey(fq, n, points, visit=None):
+    """reads up to ``n`` records of ``fq`` -- spread over ``points`` places of a plain file, all from the start of a
+    gzipped one (which cannot be entered anywhere else) -- checks each and returns a :class:`Survey`: how many were
+    read, the lowest and highest score character seen (ASCII indices) and the first record.  ``visit(record)`` is
+    called for every record.  An empty line ends the sample; behind it the file may hold empty lines only."""
+    size = None if fq.gz else os.path.getsize(fq.fname)
+    lowest, highest, count, first = 999, -999, 0, None
+    fq.fd.seek(0)
+    for place, want in enumerate(_quota(n, points)):
+        if size is not None and place:
+            fq.fd.seek(size * place // points)
+            fq.seekback()
+        for _ in range(want):
+            lines = [fq._line() for _ in range(4)]
+            if lines[0].rstrip('\r\n') == '':
+                _nothing_but_empty_lines(fq, lines[1:])
+                return Survey(count, lowest, highest, first)
+            rec = Record(*(x.rstrip('\r\n') for x in lines))
+            check_record(rec)
+            if first is None:
+                first = (rec, sum(map(len, lines)))
+            if rec.scores:
+                codes = [ord(c) - 33 for c in (min(rec.scores), max(rec.scores))]
+                lowest, highest = min(lowest, codes[0]), max(highest, codes[1])
+            if visit:
+                visit(rec)
+            count += 1
+    return Survey(count, lowest, highest, first)
+
+
+def _nothing_but_empty_lines(fq, already_read):
+    for line in itertools.chain(already_read, iter(fq._line, '')):
+        if line.rstrip('\r\n'):
+            raise FastqFileFormatException('non-empty line after empty line (fpos=%d)' % fq.fd.tell())
+
+
+# --- the record around a file position -------------------------------------------------------------------
+
+class _Backtrack(object):
+    """Line starts in front of a file position, nearest first, from blocks read backwards (one ``read`` per 64 KiB,
+    not one per line)."""
+
+    BLOCK = 1 << 16
+
+    def __init__(self, fd, pos):
+        self.fd = fd
+        self.at = pos                # everything from here to the original position has been looked at
+
+    def line_starts(self):
+        """yields the start of the line that holds the position, then of the line in front of it, ..."""
+        pending = self.at            # a line start is known to lie at or in front of this byte
+        while pending > 0:
+            lo_ = max(0, pending - self.BLOCK)
+            self.fd.seek(lo_)
+            block = self.fd.read(pending - lo_)
+            cut = len(block)
+            while True:
+                nl = block.rfind(b'\n', 0, cut)
+                if nl < 0:
+                    break
+                yield lo_ + nl + 1
+                cut = nl             # (the newline itself ends the line in front)
+            pending = lo_
+        yield 0
+
+    def first_byte(self, start):
+        self.fd.seek(start)
+        return self.fd.read(1)
+
+
+def record_start(fd, pos):
+    """start of the record whose '+' line is the nearest one at or in front of ``pos``: the position inside a record's
+    separator or score line gives that record, inside its identifier or bases the one before (0 when there is none).
+    A score line may begin with '+' as well; the separator is the '+' line whose line two above begins with '@'."""
+    back = _Backtrack(fd, pos)
+    window = collections.deque(maxlen=3)           # the last three line starts seen: [this, one below, two below]
+    for start in back.line_starts():
+        window.appendleft(start)
+        # `start` is a candidate identifier line when the line two below it (seen two steps ago) begins with '+'
+        if len(window) == 3 and back.first_byte(window[2]) == b'+' and back.first_byte(start) == b'@':
+            return start
+    return 0
+
+
+# --- the class callers know --------------------------------------------------------------------------------
+
+class Fastq(object):
+    """``kvarq.fastq.Fastq``: a look at one FastQ file (or a ``_1`` / ``_2`` pair).
+
+    After construction: ``fname``, ``fname2`` (or None), ``gz``, ``fd`` (binary file object), ``dQ`` / ``Azero`` /
+    ``variants`` (the PHRED scale), ``readlength`` (of the first record), ``records_approx`` (None for ``.gz``).
+    Text is latin-1 ``str`` (one character per byte)."""
+
+    ASCII = ASCII
+    vendor_variants = PhredScale.TABLE
+
     def __init__(self, fname, variant=None, fd=None, paired=False, quiet=False):
-        self.fname = fname
-        if fname.endswith('.fastq.gz'):
-            self.gz = True
-        elif fname.endswith('.fastq'):
-            self.gz = False
-        else:
-            raise FastqFileFormatException('fastq file must have extension ".fastq" or ".fastq.gz"')
-        self.fd = fd if fd else (gzip.GzipFile(fname, 'rb') if self.gz else open(fname, 'rb'))
-
-        # the second file of a pair (kvarq/fastq.py:90-98)
-        self.fname2 = None
-        if paired:
-            cut = fname.rindex('.fastq')
-            base = fname[:cut]
-            if base[-2:] == '_1':
-                fname2 = base[:-2] + '_2' + fname[cut:]
-                if os.path.exists(fname2):
-                    lo.info('including paired file "%s"' % fname2)
-                    self.fname2 = fname2
-
-        if sum(self.filesizes()) == 0:
+        self.fname, self.gz = fname, self._kind(fname)
+        self.fd = fd or (gzip.GzipFile(fname, 'rb') if self.gz else open(fname, 'rb'))
+        self.fname2 = self._mate(fname) if paired else None
+        if self.fname2:
+            lo.info('including paired file "%s"' % self.fname2)
+        if not any(self.filesizes()):
             raise FastqFileFormatException('cannot scan empty file')
-
-        min_pos, max_pos = self.min_max_score_check_file()
-        lo.debug('min_pos=%d max_pos=%d' % (min_pos, max_pos))
-
-        if variant and variant not in self.vendor_variants:
+        seen = self._survey()                                        # (a malformed file is reported before a bad argument, as the reference does)
+        if variant is not None and variant not in PhredScale.TABLE:
             raise FastqFileFormatException('unknown vendor variant "%s"' % variant)
-
-        # variants whose score range holds everything that was seen (kvarq/fastq.py:111-118)
-        fit = [(name, v.dQ) for name, v in self.vendor_variants.items()
-               if (min_pos - v.dQ) in v.Qrange and (max_pos - v.dQ) in v.Qrange]
-        if variant is None:
-            if not fit:
-                raise FastqFileFormatException('could not find any suitable fastq vendor variant')
-            if len(set(dq for _, dq in fit)) > 1:
-                raise FastqFileFormatException('cannot determine dQ with guessed vendor variants "%s"'
-                                               % str([name for name, _ in fit]))
-            self.variants = [name for name, _ in fit]
-            self.dQ = fit[0][1]
-        else:
-            if variant not in [name for name, _ in fit]:
-                lo.warning('specified vendor variant "%s" seems not to be compatible with file' % variant)
-            self.variants = [variant]
-            self.dQ = self.vendor_variants[variant].dQ
-        self.Azero = self.ASCII[self.dQ]
-
-        # read length of the first record, records by file size (kvarq/fastq.py:141-150)
-        self.fd.seek(0)
-        lines = [self._readline() for _ in range(4)]
-        self.readlength = len(lines[1].strip('\r\n'))
-        if self.gz:
-            self.records_approx = None
-        else:
-            self.records_approx = os.path.getsize(self.fname) // max(1, len(''.join(lines)))
-            if self.fname2 is not None:
-                self.records_approx *= 2
+        self.variants, self.dQ = self._scale(seen, variant)
+        self.Azero = ASCII[self.dQ]
+        rec, nbytes = seen.first if seen.first else (Record('', '', '', ''), 1)
+        self.readlength = len(rec.bases)
+        # records by the size of the first one; the mate of a pair is taken to hold as many
+        self.records_approx = None if self.gz else os.path.getsize(fname) // max(1, nbytes) * len(self.filenames())
         if not quiet:
-            if self.gz:
-                lo.info('gzipped fastq : readlength=? records_approx=? dQ=%d variants=%s' % (self.dQ, str(self.variants)))
-            else:
-                lo.info('fastq : readlength=%d records_approx=%d dQ=%d variants=%s'
-                        % (self.readlength, self.records_approx, self.dQ, str(self.variants)))
+            lo.info('%sfastq : readlength=%s records_approx=%s dQ=%d variants=%s'
+                    % ('gzipped ' if self.gz else '', '?' if self.gz else self.readlength, '?' if self.gz else self.records_approx, self.dQ, self.variants))
 
-    # -- files ---------------------------------------------------------------
+    # -- construction, piece by piece ------------------------------------------------------------------
+
+    @staticmethod
+    def _kind(fname):
+        for ext, gz in (('.fastq.gz', True), ('.fastq', False)):
+            if fname.endswith(ext):
+                return gz
+        raise FastqFileFormatException('fastq file must have extension ".fastq" or ".fastq.gz"')
+
+    @staticmethod
+    def _mate(fname):
+        """``x_2.fastq[.gz]`` next to ``x_1.fastq[.gz]``, when it exists (the pairing rule of kvarq/fastq.py:90-98)"""
+        stem, dot, ext = fname.rpartition('.fastq')
+        if stem.endswith('_1'):
+            mate = stem[:-2] + '_2' + dot + ext
+            if os.path.exists(mate):
+                return mate
+        return None
+
+    def _survey(self, n=1000, points=10, visit=None):
+        if self.gz:
+            lo.debug('gzipped fastq : scan %d points at start only' % n)
+        return survey(self, n, points, visit)
+
+    def _scale(self, seen, variant):
+        """-> (names, dQ): the scales that hold the scores seen; a named ``variant`` overrides the guess"""
+        fitting = PhredScale.holding(seen.lowest, seen.highest)
+        lo.debug('min_pos=%d max_pos=%d' % (seen.lowest, seen.highest))
+        if variant is not None:
+            if variant not in fitting:
+                lo.warning('specified vendor variant "%s" seems not to be compatible with file' % variant)
+            return [variant], PhredScale.offset(variant)
+        offsets = {PhredScale.offset(name) for name in fitting}
+        if not offsets:
+            raise FastqFileFormatException('could not find any suitable fastq vendor variant')
+        if len(offsets) > 1:
+            raise FastqFileFormatException('cannot determine dQ with guessed vendor variants "%s"' % fitting)
+        return fitting, offsets.pop()
+
+    # -- files -----------------------------------------------------------------------------------------
 
     def filenames(self):
-        return [self.fname, self.fname2] if self.fname2 is not None else [self.fname]
+        return [f for f in (self.fname, self.fname2) if f is not None]
 
     def filesizes(self):
         return [os.path.getsize(f) for f in self.filenames()]
 
-    def _readline(self):
+    def _line(self):
         return self.fd.readline().decode('latin-1')
 
-    # -- sampling ------------------------------------------------------------
-
-    def _sample_points(self, n, points):
-        """yields once per record to read: ``n`` records spread over ``points`` places of a plain
-        file (all of them from the start of a gzipped one), kvarq/fastq.py:182-193"""
-        self.fd.seek(0)
-        for point in range(points):
-            if not self.gz and point > 0:
-                self.fd.seek(os.path.getsize(self.fname) * point // points)
-                self.seekback()
-            while n > (points - 1 - point) * n // points:
-                yield point
-                n -= 1
+    # -- samples ---------------------------------------------------------------------------------------
 
     def min_max_score_check_file(self, n=1000, points=10):
-        """format check of a sample of records; smallest and largest score character seen, as
-        indices into ``ASCII`` (kvarq/fastq.py:170-236)"""
-        ret_min, ret_max = +999, -999
-        if self.gz:
-            lo.debug('gzipped fastq : scan %d points at start only' % n)
-        identifier = None
-        valid = set(self.ASCII)
-        sampler = self._sample_points(n, points)
-        for _ in sampler:
-            identifier = self._readline().rstrip('\n\r')
-            if not identifier:
-                break
-            if identifier[0] != '@':
-                raise FastqFileFormatException('identifier (1st line of record) must begin with "@"')
-            bases = self._readline().rstrip('\n\r')
-            if not set(bases).issubset(set('AGCTN')):
-                raise FastqFileFormatException('bases (2nd line of record) must contain only AGCTN')
-            plus = self._readline().rstrip('\n\r')
-            if not (plus == '+' or (plus[:1] == '+' and plus[1:] == identifier[1:])):
-                raise FastqFileFormatException('separator (3rd line of record) must be == "+" or "+(ident)"')
-            phredstr = self._readline().rstrip('\n\r')
-            if not (len(bases) == len(phredstr) or (len(bases) == len(phredstr) - 1 and phredstr[-1] == '!')):
-                raise FastqFileFormatException('bases must be ~ same length as phred score (2nd, 4th line)')
-            if not set(phredstr).issubset(valid):
-                raise FastqFileFormatException('phred score (4th line of record) must contain only "%s"' % self.ASCII)
-            for x in phredstr:
-                i = ord(x) - 33
-                ret_min, ret_max = min(ret_min, i), max(ret_max, i)
-        if identifier is not None and not identifier:
-            # behind an empty line there must be nothing but empty lines
-            while True:
-                line = self._readline()
-                if not line:
-                    break
-                if line.rstrip('\r\n') != '':
-                    raise FastqFileFormatException('non-empty line after empty line (fpos=%d' % self.fd.tell())
-        return ret_min, ret_max
+        """format check of a sample of records; the smallest and largest score character seen, as indices into ``ASCII``"""
+        seen = self._survey(n, points)
+        return seen.lowest, seen.highest
 
     def lengths(self, Amin, n=1000, points=10):
-        """quality-trimmed lengths of a sample of records (kvarq/fastq.py:266-293)"""
-        if self.gz:
-            lo.debug('gzipped fastq : scan %d points at start only' % n)
+        """quality-trimmed lengths (:meth:`cutoff`) of a sample of records"""
         out = []
-        for _ in self._sample_points(n, points):
-            _, _, _, scores = (self._readline().strip() for _ in range(4))
-            _, length = self.cutoff(scores, Amin)
-            if length >= 0:
-                out.append(length)
-        return out
+        self._survey(n, points, visit=lambda rec: out.append(self.cutoff(rec.scores, Amin)[1]))
+        return [x for x in out if x >= 0]
 
     @staticmethod
     def cutoff(scores, Amin):
-        """``pos, length`` of the longest CLOSED run of scores >= Amin (a run that reaches the
-        end of the line is not counted; kvarq/fastq.py:295-308 -- the engine sees a closing
-        newline and does count it, workhorse.c:1055-1068)"""
-        length, best_pos, pos = -1, 0, 0
-        for j, a in enumerate(scores):
-            if ord(a) >= ord(Amin):
-                if pos < 0:
-                    pos = j
-            else:
-                if pos >= 0 and length < j - pos:
-                    length, best_pos = j - pos, pos
-                pos = -1
-        return best_pos, length
+        """``(start, length)`` of the longest run of scores >= Amin that is CLOSED by a worse score, the first of equally
+        long ones; ``(0, -1)`` when no run is closed -- a run that reaches the end of the line does not count here
+        (kvarq/fastq.py:295-308; the engine sees the closing newline and does count it, workhorse.c:1055-1068).  A line
+        that begins with a bad score has the empty run (0, 0) closed by it."""
+        best = (0, -1)
+        at = 0
+        runs = [(good, len(list(chars))) for good, chars in itertools.groupby(scores, key=lambda c: c >= Amin)]
+        for k, (good, length) in enumerate(runs):
+            closed = good and k + 1 < len(runs)
+            if closed and length > best[1]:
+                best = (at, length)
+            if not good and k == 0 and best[1] < 0:
+                best = (0, 0)
+            at += length
+        return best
 
-    # -- PHRED arithmetic ----------------------------------------------------
+    # -- PHRED arithmetic ------------------------------------------------------------------------------
 
     def A2Q(self, A):
-        return self.ASCII.index(A) - self.dQ
+        return ASCII.index(A) - self.dQ
 
     def Q2A(self, Q):
-        return self.ASCII[Q + self.dQ]
+        return ASCII[Q + self.dQ]
 
     @staticmethod
     def Q2p(Q):
@@ -229,59 +308,29 @@ class Fastq(object):
     def p2Q(p):
         return int(-10 * math.log(p) / math.log(10))
 
-    # -- records around a file position --------------------------------------
+    # -- records and hits by file position ---------------------------------------------------------------
 
     def seekback(self):
-        """moves the file position to the start of the current record (when it stands behind the
-        record's '+' line) or of the previous one (when it stands in front of it), kvarq/fastq.py:331-350.
-
-        Walks up line by line to a '+' line whose line two above starts with '@' (a score line
-        may start with '+' too, but then the line two above holds bases)."""
-        starts = []                                    # starts of the lines walked over, nearest first
-        pos = self._line_start(self.fd.tell())
-        while True:
-            starts.append(pos)
-            self.fd.seek(pos)
-            line = self._readline()
-            if line[:1] == '+' and pos > 0:
-                up1 = self._line_start(pos - 1)
-                up2 = self._line_start(up1 - 1) if up1 > 0 else 0
-                self.fd.seek(up2)
-                if self._readline()[:1] == '@' and up1 > 0:
-                    self.fd.seek(up2)
-                    return
-            if pos == 0:
-                self.fd.seek(0)
-                return
-            pos = self._line_start(pos - 1)
-
-    def _line_start(self, pos):
-        """start of the line that holds byte ``pos``"""
-        step = 4096
-        while pos > 0:
-            lo_ = max(0, pos - step)
-            self.fd.seek(lo_)
-            chunk = self.fd.read(pos - lo_)
-            k = chunk.rfind(b'\n')
-            if k >= 0:
-                return lo_ + k + 1
-            pos = lo_
-        return 0
+        """moves the file position to the start of the record it stands in (behind the record's '+' line) or of the one
+        before (in front of it): see :func:`record_start`"""
+        self.fd.seek(record_start(self.fd, self.fd.tell()))
 
     def readrecord(self):
-        return tuple(self._readline().strip() for _ in range(4))
+        return tuple(self._line().strip() for _ in range(4))
 
     def readrecordat(self, hit):
-        """the four lines of the record a hit lies in (kvarq/fastq.py:374-381)"""
+        """the four lines of the record a hit lies in: its bases stand in front of the '+' line, so the record found
+        from the hit's position is the one before"""
         self.fd.seek(hit.file_pos)
         self.seekback()
         self.readrecord()
         return '\n'.join(self.readrecord()) + '\n'
 
     def readhit(self, hit):
-        """the bases of a hit as they stand in the file (kvarq/fastq.py:310-318)"""
-        self.fd.seek(hit.file_pos - hit.seq_pos if hit.seq_pos < 0 else hit.file_pos)
+        """the bases of a hit as they stand in the file (``file_pos`` is where the trimmed read begins; a hit that
+        starts inside the read has a negative ``seq_pos``)"""
+        self.fd.seek(hit.file_pos + max(0, -hit.seq_pos))
         return self.fd.read(hit.length).decode('latin-1')
 
     def readhits(self, hits):
-        return [self.readhit(hit) for hit in hits]
+        return list(map(self.readhit, hits))

@@ -102,6 +102,7 @@ class Scanner(object):
         if not self.h:
             _raise_last()
         self._host_batches = []          # copies of what scan_host was given since the last reset (fed again when the hit arena overflows)
+        self._device_batches = []        # what scan_device was given since the last reset (the caller's device memory: nothing is copied)
         self._retained, self._retain_limit, self._replay = 0, (0 if replay is not None else retain_limit), replay
         self._comm = None
 
@@ -121,7 +122,12 @@ class Scanner(object):
 
     def scan_device(self, d_ptr, nbytes, chunk_off, fpos_base=0):
         co = np.ascontiguousarray(chunk_off, dtype=np.int64)
+        self._device_batches.append((d_ptr, nbytes, co, fpos_base))
         _check(_lib.lib().kvq_scan_device(self.h, d_ptr, nbytes, co.ctypes.data_as(C.POINTER(C.c_int64)), len(co) - 1, fpos_base))
+
+    def _feed_host(self, arr, co, fpos_base):
+        _check(_lib.lib().kvq_scan_host(self.h, arr.ctypes.data if arr.nbytes else None, arr.nbytes,
+                                        co.ctypes.data_as(C.POINTER(C.c_int64)), len(co) - 1, fpos_base))
 
     def scan_host(self, data, chunk_off=None, fpos_base=0):
         arr = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
@@ -131,8 +137,7 @@ class Scanner(object):
                 self._host_batches.append((arr.copy(), co.copy(), fpos_base)); self._retained += arr.nbytes
             else:
                 self._host_batches = None          # too much to keep: an overflow is the caller's to replay
-        _check(_lib.lib().kvq_scan_host(self.h, arr.ctypes.data if arr.nbytes else None, arr.nbytes,
-                                        co.ctypes.data_as(C.POINTER(C.c_int64)), len(co) - 1, fpos_base))
+        self._feed_host(arr, co, fpos_base)
 
     def finish(self, hits=True, stats=True):
         """-> dict with 'hits', 'hitseqs' (bytes), 'stats', 'coverage', 'mutations', 'counters'.
@@ -147,15 +152,24 @@ class Scanner(object):
             if _lib.last_error()[0] != _lib.ERR_RESCAN or attempt == 3:
                 _raise_last()
             # the hit arena was too small for the host batches (it has been enlarged): feed them again
-            again, replay = self._host_batches, self._replay
+            # (with a communicator the overflow may be another rank's: every rank goes round again, whatever it was fed with)
+            again, device, replay = self._host_batches, self._device_batches, self._replay
             if again is None and replay is None:
                 raise RescanRequired(_lib.last_error()[1])
+            if replay is None and not again and not device:
+                raise RescanRequired('nothing to feed again: ' + str(_lib.last_error()[1]))
+            retained = self._retained
             self.reset()
             if replay is not None:
                 replay(self)
             else:
+                # the kept copies go in again as they are (no second copy, and they stay kept: a further round may want them);
+                # device batches are the caller's memory and are simply named again
+                self._host_batches, self._retained = again, retained
                 for arr, co, fpos_base in again:
-                    self.scan_host(arr, co, fpos_base)
+                    self._feed_host(arr, co, fpos_base)
+                for d_ptr, nbytes, co, fpos_base in device:
+                    self.scan_device(d_ptr, nbytes, co, fpos_base)
         t = self.table
         ctr = _view(L.kvq_scan_counters(self.h), t.counters_len, C.c_int64, np.int64)
         if stats:
@@ -212,7 +226,7 @@ class Scanner(object):
         return {'n_hits': nh, 'hits': hits, 'hitseqs': [blob[off[i]:off[i + 1]] for i in range(nh)]}
 
     def reset(self):
-        self._host_batches = []
+        self._host_batches, self._device_batches, self._retained = [], [], 0
         _check(_lib.lib().kvq_scan_reset(self.h))
 
     def close(self):

@@ -196,6 +196,7 @@ def chunk_offsets(data):
 # ---------------------------------------------------------------------------
 
 _ref_engine = None
+_ref_modules = {}
 
 
 def ref_engine():
@@ -214,9 +215,12 @@ def ref_engine():
             _ref_engine = False
         finally:
             sys.path.remove(d)
-            # keep the stub package reachable for the extension, restore anything we displaced
-            for k, v in saved.items():
-                sys.modules.setdefault(k, v)
+            # the stub package the extension resolved its collaborators from stays alive here (the extension holds the objects it
+            # looked up at import), but NOT under the name `kvarq`: that name belongs to whatever had it before -- the product's
+            # own kvarq/ shim package when a test imports it -- so `from kvarq import engine` never means the reference build
+            global _ref_modules
+            _ref_modules = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'kvarq' or k.startswith('kvarq.')}
+            sys.modules.update(saved)
     return _ref_engine or None
 
 

@@ -497,6 +497,30 @@ def test_an_empty_or_refused_batch_leaves_no_hole():
     s.close(); t.close(); d.free(); d2.free()
 
 
+def test_a_batch_of_empty_chunks_behind_a_batch_with_skipped_tiles():
+    """A batch whose chunks are all empty scans no tile; the redo chain behind it must not run on the counts the batch in
+    front of it left (a tile of that batch skipped its 5 kB record: one record on the redo's list)."""
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g))
+    plain = synth.reads(g, 0, 2000, 150)
+    big = bytes(g[1000:6000])
+    rec = b'@big 1:N:0\n' + big + b'\n+\n' + b'I' * len(big) + b'\n'
+    rb = synth.record_bytes(150)
+    text = np.frombuffer(plain[:108 * rb].tobytes() + rec + plain[108 * rb:].tobytes(), dtype=np.uint8)
+    want = O.scan_memory(text, seqs, nthreads=2, **cases.PRODUCT)
+    t = scan.Table(seqs, **cases.PRODUCT)
+    s = scan.Scanner(t)
+    d = scan.DeviceBuffer(text.nbytes); d.upload(text)
+    s.scan_device(d.ptr, text.nbytes, scan.chunk_offsets(text))
+    s.scan_device(d.ptr, 0, np.zeros(2, dtype=np.int64), fpos_base=text.nbytes)       # one empty chunk
+    s.scan_device(d.ptr, 0, np.zeros(3, dtype=np.int64), fpos_base=text.nbytes)       # two of them
+    r = s.finish()
+    assert r['path']['tiles_rescanned'] and r['stats']['records_parsed'] == 2001
+    assert tuple(r['hits']) == tuple(want['hits']) and r['stats']['nseqhits'] == want['stats']['nseqhits']
+    assert r['stats']['readlengths'] == want['stats']['readlengths']
+    s.close(); t.close(); d.free()
+
+
 def test_native_rccl_communicator_of_one_rank():
     """the library's own RCCL entry points (include/kvarq_hip.h, "several GPUs") on the one GPU there is: a
     communicator of one rank; finish sums the counters over it (all-reduce, maximum for the longest read) and
@@ -622,6 +646,32 @@ def test_arena_overflow_on_one_rank_takes_every_rank_round_again():
     assert [o[1] for o in outs] == [600 + 40000 * 60] * 2 and [o[2] for o in outs] == [600, 40000 * 60]
     assert [o[3] for o in outs] == [60010] * 2
     t.close()
+
+
+def test_replay_of_kept_host_batches_neither_copies_them_again_nor_forgets_them():
+    """Scanner.finish feeds its kept copies again when the hit arena overflows.  The copies are kept once: with a retain limit
+    between one and two times the data the replay must not count them a second time (and drop them, so that a further
+    overflow could not be served), and reset() starts the count afresh however often a Scanner is reused."""
+    read = 'ACG' * 60
+    data = np.frombuffer(cases.rec('x', read, 'I' * len(read)) * 40000, dtype=np.uint8)          # 2.4 M hits: the arena starts at 1 M
+    t = scan.Table([b'ACG'], **dict(cases.DEFAULTS, minreadlength=10))
+    s = scan.Scanner(t, retain_limit=data.nbytes * 3 // 2)
+    for round_ in range(3):                                                    # (the arena stays enlarged: only the first round overflows)
+        s.scan_host(data)
+        r = s.finish(hits=False)
+        assert int(r['counters'][t.off_nseqhits]) == 40000 * 60 and int(r['counters'][_lib.CTR_RECORDS]) == 40000
+        assert s._host_batches is not None and len(s._host_batches) == 1 and s._retained == data.nbytes
+        s.reset()
+        assert s._host_batches == [] and s._retained == 0
+    # a device batch goes round again too (the caller's memory is named again, not copied)
+    d = scan.DeviceBuffer(data.nbytes); d.upload(data)
+    t2 = scan.Table([b'ACG', b'CGA'], **dict(cases.DEFAULTS, minreadlength=10))      # (a fresh table and scan: a fresh arena)
+    s2 = scan.Scanner(t2)
+    s2.scan_host(data[:len(data) // 2], fpos_base=0)
+    s2.scan_device(d.ptr + 0, data.nbytes, scan.chunk_offsets(data), fpos_base=data.nbytes)
+    r2 = s2.finish(hits=False)
+    assert int(r2['counters'][_lib.CTR_RECORDS]) == 60000 and int(r2['counters'][t2.off_nseqhits]) == 60000 * 60
+    s.close(); s2.close(); t.close(); t2.close(); d.free()
 
 
 def test_one_long_record_costs_its_tile_not_the_batch():
