@@ -69,6 +69,8 @@ def main():
     ap.add_argument('--readlen', type=int, default=150)
     ap.add_argument('--table', default='MTBC', choices=['MTBC', 'MTBC+barcodes'])
     ap.add_argument('--table-scale', type=int, default=1)
+    ap.add_argument('--maxerrors', type=int, default=2, help='engine setting (product default 2; kvarq/cli.py:410-427 exposes it)')
+    ap.add_argument('--minoverlap', type=int, default=25, help='engine setting (product default 25)')
     ap.add_argument('--exhaustive', action='store_true', help='force the exhaustive kernel for every sequence')
     ap.add_argument('--pipeline', type=int, default=0,
                     help='scans in flight: step k+1 is enqueued (on its own scan object and stream) before the results of step k '
@@ -137,7 +139,7 @@ def main():
     g = synth.genome()
     plus = synth.table(g, args.table, scale=args.table_scale)
     seqs = synth.both_strands(plus)
-    cfg = dict(maxerrors=2, minoverlap=25, minreadlength=25, Amin='.')     # kvarq/config.py:2-10
+    cfg = dict(maxerrors=args.maxerrors, minoverlap=args.minoverlap, minreadlength=25, Amin='.')     # kvarq/config.py:2-10
     d_genome = scan.DeviceBuffer(g.nbytes)
     d_genome.upload(g)
     d_data = scan.DeviceBuffer(n * rb)
@@ -322,10 +324,11 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'strong' if args.total_reads else 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
         'config': {'workload': '%s%d x %d bp synthetic FastQ per GPU (%d B/record, resident in HBM) vs %s table '
-                               '(%d templates, both strands = %d sequences, %d bases); e=2, minoverlap=25, minreadlength=25, Amin=\'.\''
+                               '(%d templates, both strands = %d sequences, %d bases); e=%d, minoverlap=%d, minreadlength=25, Amin=\'.\''
                                % ('%d x %d bp in all, read-sharded over %d GPUs = ' % (args.total_reads, L, world) if args.total_reads else '',
-                                  n, L, rb, args.table, len(plus), len(seqs), sum(map(len, seqs))),
-                   'baseline_config': ('configs[3]' if args.total_reads == 40_000_000 and world == 8 and L == 150 and args.table == 'MTBC' else
+                                  n, L, rb, args.table, len(plus), len(seqs), sum(map(len, seqs)), args.maxerrors, args.minoverlap),
+                   'baseline_config': (None if (args.maxerrors, args.minoverlap) != (2, 25) else
+                                       'configs[3]' if args.total_reads == 40_000_000 and world == 8 and L == 150 and args.table == 'MTBC' else
                                        'configs[2]' if n == 10_000_000 and L == 150 and args.table == 'MTBC' and args.table_scale == 1 else
                                        'configs[1]' if n == 1_000_000 and L == 150 and args.table == 'MTBC' and args.table_scale == 1 else None),
                    'total_reads': world * n,
