@@ -341,7 +341,10 @@ __device__ __forceinline__ void bp_runs64(uint64_t m, int n, uint32_t dbg, int &
 // DIAG: the kernel honours the KVQ_DBG switches (ablations, forced paths); the production instantiations do not carry them
 // KK: the seed length the table's index was built with (kvq_seed_k: 8 at the product settings, 5 to 7 where (maxerrors + 1) * 8
 // does not fit the shortest accepted overlap)
-template <int SS, int LG, bool STAMPS, bool DIAG = STAMPS, int KK = 8>
+// DENSE: the instantiation for tables and settings that give candidates by the dozen per read (kvq_seed_index_build estimates them from the
+// bitmaps' occupancy: seeds shorter than 8, the MTBC table x 8 and beyond): the queues are drained as they fill instead of the stretch being
+// halved and filtered again
+template <int SS, int LG, bool STAMPS, bool DIAG = STAMPS, int KK = 8, bool DENSE = (KK < 8)>
 __global__ void __launch_bounds__(ST_THREADS, BP_OCC)
 kvq_scan_bp(const BpArgs *__restrict__ A_)
 {
@@ -749,46 +752,10 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 const bool thit = fixed_block(rl - ((int)gl + 1) * KK, tail_ok((int)gl));
                 constexpr int NR = SS == 8 ? 6 : SS == 4 ? 12 : (LG == 3 || LG == 1) ? 24 : 18;  // lookups per lane and round (18: a 150-base read's 72 even positions over four lanes; 24: a 300-base read's 147 over eight -- 19 a lane -- or a 100-base read's 47 over two, one round instead of two)
                 bool first = true;
+                if constexpr (!DENSE) {
                 for (int ee = e0; __any(ee < e1); ee += NR, first = false) {
                     const bool act = ee < e1;
-                    uint32_t hA = 0;                                             // bit j: lookup ee + j met an anchor code
-                    {
-                        // the read's bases are a bit range of the code plane: position roff + SS * ee on
-                        const uint32_t pos = roff + (uint32_t)SS * (uint32_t)(act ? ee : 0);
-                        const uint32_t a = (pos >> 2) & ~3u, bo = (pos & 15u) * 2u;
-                        constexpr int NW = (2 * SS * (NR - 1) + 16 + 31) / 32 + 1;   // words that hold NR codes at any alignment
-                        uint32_t W[NW];
-#pragma unroll
-                        for (int t = 0; t < NW; t++) W[t] = lds_u32_at(a + 4u * (uint32_t)t);
-                        uint32_t R[NW - 1];
-#pragma unroll
-                        for (int t = 0; t < NW - 1; t++) R[t] = __builtin_amdgcn_alignbit(W[t + 1], W[t], bo);
-                        // (round 4: a lookup in six two-cycle instructions instead of four four-cycle ones -- the bitmap is read a word at a time, the
-                        // shift that brings the code's bit down takes its five low bits from the code itself, and the hits are shifted in from the
-                        // last lookup to the first by an add and a three-input logic op: no v_bfe, no v_lshl_or)
-                        constexpr int NB = 6;
-                        static_assert(NR % NB == 0, "whole batches of lookups");
-#pragma unroll
-                        for (int j0 = NR - NB; j0 >= 0; j0 -= NB) {
-                            uint32_t bi[NB], bb[NB];
-#pragma unroll
-                            for (int u = 0; u < NB; u++) {
-                                const int b = 2 * SS * (j0 + u), wj = b >> 5, o = b & 31;
-                                // the code is bits o .. o + 15 of R[wj] (and of R[wj + 1] when it crosses the word)
-                                const uint32_t word = o <= 16 ? R[wj] : __builtin_amdgcn_alignbit(R[wj + 1 < NW - 1 ? wj + 1 : wj], R[wj], 16);
-                                const uint32_t off = (uint32_t)(o <= 16 ? o : o - 16);
-                                bi[u] = word >> off;                                                        // (its low five bits: the code's)
-                                bb[u] = lds_u32_at(BP_LDS_BMA + ((word >> (off + 3u)) & (((1u << (2 * KK - 3)) - 1u) & ~3u)));          // the bitmap word of code >> 5
-                            }
-                            asm volatile("" ::: "memory");
-#pragma unroll
-                            for (int u = NB - 1; u >= 0; u--) {
-                                uint32_t h2;
-                                asm("v_add_u32 %0, %1, %1" : "=v"(h2) : "v"(hA));                            // (hA << 1 by the two-cycle adder: the compiler's v_lshlrev takes four)
-                                hA = __builtin_amdgcn_bitop3_b32(h2, bb[u] >> (bi[u] & 31u), 1u, 0xF8);      // a | (b & c)
-                            }
-                        }
-                    }
+#include "kernels_bp_lookup.inc"
                     const int nv = act ? (e1 - ee < NR ? e1 - ee : NR) : 0;
                     hA &= (1u << nv) - 1u;                                      // nv <= 24
                     const bool hh = first && hhit, th = first && thit;
@@ -822,6 +789,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                         }
                     }
                 }
+                }   // !DENSE
         KVQ_MARK("filter end / P4a");
                 BSTAMP(5);
                 KVQ_SETPRIO(3);
@@ -830,6 +798,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                 // as 2-bit codes against the entry's own copy of the sequence around the seed (SeedEntry::ctx; equal bytes have equal
                 // codes, so this only ever rejects, and nearly every false candidate ends here: TWO dependent loads, code -> range of
                 // entries -> entry; round 3 went on to the 2-bit table for the bases) -> what is left goes through bp_verify_rest ----
+                if constexpr (!DENSE) {
                 const bool over = qn > BP_QW;                             // candidates were dropped
                 const uint32_t qn_ok = (over || (dbg & 1u)) ? 0u : qn;
                 if (over && step > 1u) { step >>= 1; continue; }
@@ -856,70 +825,67 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                         else atomicOr(A->fail, 2u);                      // (reported as records that went through the exhaustive kernels; the next launches of this scan object use the wide grids)
                     }
                 }
-                if (qn_ok) {
-                    typedef const __attribute__((address_space(1))) u32x4_t *GlbEntries;
-                    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-                    typedef const __attribute__((address_space(1))) u32x2_t __attribute__((aligned(4))) *GlbPairs;
-                    BpHot H; GlbWords start; GlbEntries ent; int64_t tile_fpos; int need;
-                    {
-                        const BpArgsPtr A = bp_args(A_);
-                        H.cold = &A_->P; H.tab = (GlbBytes)A->P.tab; H.tab2 = (GlbWords)A->X.tab2; H.maxerrors = me_; H.minoverlap = A->P.minoverlap; H.pitch = A->X.pitch;
-                        start = (GlbWords)A->X.start; ent = (GlbEntries)A->X.ent;
-                        tile_fpos = A->fpos_base + (int64_t)g0;
-                        need = (me_ + 1) * KK;                            // no alignment is shorter (kvq_seed_index_build)
-                    }
-                    // (the items are numbered in candidate order; the queue takes BP_Q2W of them a round -- one round, unless a read matches
-                    // dozens of sequences of a dense table: then the candidates, a hundred at most, are simply walked again for the next window)
-                    for (uint32_t w0 = 0; ; w0 += BP_Q2W) {
-                        uint32_t run = 0;
-                        for (uint32_t q0 = 0; q0 < qn_ok; q0 += 64u) {
-                            const uint32_t qi = q0 + lane;
-                            uint32_t en0 = 0, ne = 0;
-                            if (qi < qn_ok) {
-                                const uint32_t cd = q1[qi];
-                                const uint32_t code = cdp_code<KK>((S.rinfo[cd & 511u] & 0xFFFFu) + ((cd >> 9) & 0xFFFFu));
-                                const u32x2_t st = *(GlbPairs)(start + (code | ((cd >> BP_Q1_KIND) << (2 * KK))));      // (the ALL index's codes follow the anchors')
-                                en0 = st.x; ne = st.y - st.x;
-                            }
-                            const uint32_t inc = kvq_wave_incl_scan(ne);
-                            const uint32_t base = run + inc - ne - w0;                          // (unsigned: items in front of w0 wrap beyond the queue)
-                            for (uint32_t j = 0; j < ne; j++)
-                                if (base + j < BP_Q2W) q2[base + j] = (qi << 22) | (en0 + j);
-                            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                        }
-        KVQ_MARK("P4b");
-                        const uint32_t n_items = run - w0 < BP_Q2W ? run - w0 : BP_Q2W;
-                        for (uint32_t i0 = 0; i0 < n_items; i0 += 64u) {
-                            const uint32_t ii = i0 + lane;
-                            bool alive = false;
-                            uint32_t kind = 0, croff = 0, en_lo = 0, en_hi = 0; int p = 0, crl = 0;
-                            if (ii < n_items) {
-                                const uint32_t it = q2[ii];
-                                const u32x4_t E = ent[it & 0x3FFFFFu];
-                                const uint32_t cd = q1[it >> 22];
-                                p = (int)((cd >> 9) & 0xFFFFu); kind = cd >> BP_Q1_KIND;
-                                const uint32_t ri = S.rinfo[cd & 511u];
-                                croff = ri & 0xFFFFu; crl = (int)(ri >> 16);
-                                en_lo = E.x; en_hi = E.y;
-                                const int q = (int)(E.x & 4095u), seql = (int)(E.y >> 20);
-                                const int d = q - p;                     // sequence index = read index + d
-                                const int a = d < 0 ? -d : 0;
-                                const int L = (crl < seql - d ? crl : seql - d) - a;
-                                if (L >= need) {
-                                    // a window of min(L, 16) bases of the diagonal that lies inside the entry's 32: at the seed, or flush with the end of the overlap
-                                    const int wn = L < 16 ? L : 16;
-                                    const int w = p < a + L - wn ? p : a + L - wn;
-                                    const uint32_t sh = 2u * (uint32_t)(w - p + 16);          // 0 .. 32
-                                    const uint32_t seqw = (uint32_t)((((uint64_t)E.w << 32) | E.z) >> sh);
-                                    const uint32_t v = cdp32(croff + (uint32_t)w) ^ seqw;
-                                    uint32_t dm = (v | (v >> 1)) & 0x55555555u;
-                                    if (wn < 16) dm &= (1u << (2 * wn)) - 1u;
-                                    alive = __popc(dm) <= me_;
+#include "kernels_bp_p4.inc"
+                } else {
+                    // ---- dense tables, short seeds: candidates by the dozen per read (round 4).  Nothing is dropped and nothing filtered twice:
+                    // the lanes push what a round of lookups found as far as the queue has room, the queue is drained (the work items of its
+                    // candidates verified), and the pushing goes on where it stopped; the sparse kernel halves the stretch and filters it again
+                    // when a queue overflows -- up to six times per stretch with the MTBC table x 8 ----
+                    uint32_t hA = 0, hpos = 0, tpos = 0; bool hh = false, th = false;
+                    int ee = e0, xt = (int)G;
+                    auto gen_next = [&]() -> bool {
+                        if (__any(ee < e1)) {
+                            {
+                                const bool act = ee < e1;
+                                uint32_t hA_;
+                                {
+#include "kernels_bp_lookup.inc"
+                                    hA_ = hA;
                                 }
+                                const int nv = act ? (e1 - ee < NR ? e1 - ee : NR) : 0;
+                                hA = hA_ & ((1u << nv) - 1u);
                             }
-                            if (__any(alive)) bp_verify_rest<KK>(H, text, alive, croff, crl, p, kind, en_lo, en_hi, tile_fpos, SS);
+                            if (first) { hh = hhit; th = thit; hpos = gl * KK; tpos = (uint32_t)(rl - ((int)gl + 1) * KK); first = false; }
+                            ee += NR;
+                            return true;
                         }
-                        if (run <= w0 + BP_Q2W) break;
+                        if (xt <= me_) {                                        // groups narrower than e + 1 lanes: the remaining head and tail blocks
+                            const int jj = xt + (int)gl;
+                            hpos = (uint32_t)(jj * KK); tpos = (uint32_t)(rl - (jj + 1) * KK);
+                            hh = fixed_block((int)hpos, head_ok(jj)); th = fixed_block((int)tpos, tail_ok(jj));
+                            xt += (int)G;
+                            return true;
+                        }
+                        return false;
+                    };
+                    int ee_of_hA = e0;                                          // the round the pending anchor bits belong to
+                    bool done = false;
+                    while (!done) {
+                        bool full = false;
+                        while (!full) {
+                            if (!__any(hA != 0u || hh || th)) {
+                                ee_of_hA = ee;
+                                if (!gen_next()) { done = true; break; }
+                                continue;
+                            }
+                            const uint32_t c = (uint32_t)__popc(hA) + (hh ? 1u : 0u) + (th ? 1u : 0u);
+                            const uint32_t inc = kvq_wave_incl_scan(c);
+                            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                            uint32_t idx = qn + inc - c;
+                            while (hA && idx < BP_QW) {
+                                const int j = __ffs((int)hA) - 1; hA &= hA - 1u;
+                                q1[idx++] = k | ((uint32_t)(SS * (ee_of_hA + j)) << 9);
+                            }
+                            if (hh && idx < BP_QW) { q1[idx++] = k | (hpos << 9) | (1u << BP_Q1_KIND); hh = false; }
+                            if (th && idx < BP_QW) { q1[idx++] = k | (tpos << 9) | (1u << BP_Q1_KIND); th = false; }
+                            full = qn + tot >= BP_QW;
+                            qn = qn + tot < BP_QW ? qn + tot : BP_QW;
+                        }
+                        {
+                            const uint32_t qn_ok = (dbg & 1u) ? 0u : qn;
+#include "kernels_bp_p4.inc"
+                        }
+                        qn = 0;
                     }
                 }
                 KVQ_SETPRIO(2);

@@ -65,6 +65,7 @@ struct SeedIndex {
     int stride = 2;           // anchor blocks sit at sequence offsets K j + 0 .. K j + stride - 1
     int k = 8;                // seed length
     int pitch = 8;            // distance of a sequence's anchor blocks: K rounded up to a multiple of the stride
+    bool dense = false;       // candidates by the dozen per read are to be expected: the kernels that drain their queues as they fill
     DevBuf d_bm1, d_start, d_ent, d_tab2;
     SeedTables dev;
 };
@@ -157,6 +158,14 @@ SeedIndex *kvq_seed_index_build(kvq_table *t)
     for (size_t i = 0; i < v.size(); i++) {
         bm1[v[i].key >> 3] |= (uint8_t)(1u << (v[i].key & 7));                  // (bit 2K of the key = the second bitmap)
         start[v[i].key + 1]++; ent[i] = v[i].e;
+    }
+    {
+        // candidates a 150-base read of random bases would give: its lookups against the anchors' bitmap, its 2 (e + 1) fixed blocks
+        // against the one of all positions.  More than the wave's queue holds for its sixteen reads: the draining kernels.
+        size_t occ_anc = 0, occ_all = 0;
+        for (uint32_t c = 0; c < NC; c++) { occ_anc += start[c + 1] != 0; occ_all += start[NC + c + 1] != 0; }
+        const double expect = (double)occ_anc / NC * (150.0 / stride) + (double)occ_all / NC * 2 * (e + 1);
+        ix->dense = expect > 5.0;
     }
     for (uint32_t c = 0; c < 2 * NC; c++) start[c + 1] += start[c];
     start[2 * (size_t)NC + 1] = start[2 * (size_t)NC];

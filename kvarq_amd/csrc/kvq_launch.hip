@@ -130,9 +130,14 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
                                                 kvq_scan_bp<2, 2, false, true, 6>, kvq_scan_bp<4, 2, false, true, 6>, kvq_scan_bp<8, 2, false, true, 6> };
         static const BpKernel kernels_k7[6] = { kvq_scan_bp<2, -1, false, true, 7>, kvq_scan_bp<4, -1, false, true, 7>, kvq_scan_bp<8, -1, false, true, 7>,
                                                 kvq_scan_bp<2, 2, false, true, 7>, kvq_scan_bp<4, 2, false, true, 7>, kvq_scan_bp<8, 2, false, true, 7> };
-        const bool diag = ((dbg & ~16u) && !st) || ix->k != 8;
+        // (8-base seeds on a table that is dense in the code space: the draining kernels)
+        static const BpKernel kernels_dense[6] = { kvq_scan_bp<2, -1, false, true, 8, true>, kvq_scan_bp<4, -1, false, true, 8, true>, kvq_scan_bp<8, -1, false, true, 8, true>,
+                                                   kvq_scan_bp<2, 2, false, true, 8, true>, kvq_scan_bp<4, 2, false, true, 8, true>, kvq_scan_bp<8, 2, false, true, 8, true> };
+        static const int dense_env = getenv("KVQ_DENSE") ? atoi(getenv("KVQ_DENSE")) : -1;      // (tests: 1 forces the draining kernels, 0 the halving ones)
+        const bool dense = ix->k == 8 && !st && (dense_env >= 0 ? dense_env != 0 : ix->dense);
+        const bool diag = ((dbg & ~16u) && !st) || ix->k != 8 || dense;
         if (diag && lg != 2) lg = -1;
-        const BpKernel *const dk = ix->k == 5 ? kernels_k5 : ix->k == 6 ? kernels_k6 : ix->k == 7 ? kernels_k7 : kernels_diag;
+        const BpKernel *const dk = ix->k == 5 ? kernels_k5 : ix->k == 6 ? kernels_k6 : ix->k == 7 ? kernels_k7 : dense ? kernels_dense : kernels_diag;
         const BpKernel kern = diag ? dk[(lg == 2 ? 3 : 0) + si] : kernels_bp[lg == 3 ? 12 + si : lg == 1 ? 15 + si : (lg == 2 ? 6 : 0) + si + st];
         hipLaunchKernelGGL(kern, dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
     }

@@ -811,7 +811,10 @@ def test_a_read_that_floods_its_waves_queues_is_matched_on_its_own():
         s.reset()
         s.scan_device(d.ptr, text.nbytes, co)
         r = s.finish()
-        assert r['path'] == REDO_PATH, r['path']                   # (records behind the scan, not the batch again)
+        if os.environ.get('KVQ_DENSE') == '1':                      # (the draining kernels take such a read themselves: nothing is left for the redo)
+            assert r['path'] == dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False), r['path']
+        else:
+            assert r['path'] == REDO_PATH, r['path']               # (records behind the scan, not the batch again)
         assert tuple(r['hits']) == tuple(o['hits']) and r['hitseqs'] == o['hitseqs']
         assert r['coverage'].tolist() == o['coverage'] and r['mutations'].tolist() == o['mutations']
         assert r['stats']['records_parsed'] == n + len(flood) and r['stats']['readlengths'] == o['stats']['readlengths']
