@@ -265,6 +265,12 @@ def main():
             total_records = int(ctr[_lib.CTR_RECORDS].item())
             total_hits = int(ctr[_lib.CTR_HITS].item())
             assert int(r['counters'][_lib.CTR_RECORDS]) == n, 'records lost: %d of %d' % (int(r['counters'][_lib.CTR_RECORDS]), n)
+            # the fallback reducer against an independent sum: every rank's own hit and record count of the last step, summed as plain numbers
+            own = torch.tensor([int(r['n_hits']), int(r['counters'][_lib.CTR_RECORDS])], dtype=torch.int64, device='cuda')
+            dist.all_reduce(own, op=dist.ReduceOp.SUM)
+            same = int(own[0].item()) == total_hits and int(own[1].item()) == total_records
+            join_checked = ('hits and records of the last step in the summed counter array == sum over the ranks of their own counts (fallback reducer: %s)' % reduce_by
+                            if same else 'MISMATCH: the summed counter array disagrees with the ranks\' own counts')
         else:                                        # (the library's host copy of the counters is the sum over all ranks)
             total_records = int(r['counters'][_lib.CTR_RECORDS])
             total_hits = int(r['counters'][_lib.CTR_HITS])

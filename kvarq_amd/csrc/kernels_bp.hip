@@ -356,6 +356,15 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_t = 0, wave_p34 = 0;
     // (instrumented build: the workgroup's life on the constant 100 MHz clock -- entry, end of the prologue, end of its first tile, exit)
     unsigned long long rt_in = 0, rt_pro = 0, rt_first = 0;
+    // (build with -DKVQ_TALLY, instrumented instantiation: what P4 eats -- per-lane tallies, summed into spare counter slots at the end:
+    // 0 anchor candidates, 1 fixed-block candidates, 2 work items (index entries tested), 3 items that passed the 16-base test,
+    // 4 rounds of the work-item loop (per wave), 5 candidate batches (per wave), 6 stretches (per wave), 7 calls of the byte-exact part (per wave))
+    uint32_t tally[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#ifdef KVQ_TALLY          // (a build of its own: the tallies cost the instrumented kernel registers it does not have)
+#define BTALLY(i, cond) do { if constexpr (STAMPS) { if (cond) tally[i]++; } } while (0)
+#else
+#define BTALLY(i, cond) ((void)0)
+#endif
     if constexpr (STAMPS) rt_in = __builtin_amdgcn_s_memrealtime();
 #define BSTAMP(i) do { if constexpr (STAMPS) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
 
@@ -723,6 +732,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
             uint32_t *const q1 = S.q1 + wave * BP_QW; uint32_t *const q2 = S.q2 + wave * BP_Q2W;
             uint32_t sub = (dbg & 128u) ? npass : 0u, step = rpw;             // (diagnostic 128: trim only)
             while (sub < npass) {
+                BTALLY(6, lane == 0);
                 int minrl, me_; const __attribute__((address_space(1))) uint8_t *bmL;
                 {
                     const BpArgsPtr A = bp_args(A_);
@@ -928,6 +938,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     unsigned long long *const ctr = (bp_args(A_)->P.ctr + (size_t)(blockIdx.x % KVQ_STAGE_COPIES) * KVQ_STAGE_SLOTS);
     if constexpr (STAMPS) {
         if (tid == 0) for (int i = 0; i < 8; i++) atomicAdd(&ctr[KVQ_CTR_RL_ + 900 + i], stamp_acc[i]);
+        for (int i = 0; i < 8; i++) if (tally[i]) atomicAdd(&ctr[KVQ_CTR_RL_ + 930 + i], (unsigned long long)tally[i]);
         if (lane == 0) atomicAdd(&ctr[KVQ_CTR_RL_ + 908 + wave], wave_p34);
         if (tid == 0) {
             const unsigned long long rt_out = __builtin_amdgcn_s_memrealtime();

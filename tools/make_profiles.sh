@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates the measurement artifacts under profiles/ on an MI355X box (run through gpurun from the
-# repo root: `gpurun --timeout 1200 -- "KVQ_GIT_HEAD=$(git rev-parse HEAD) bash tools/make_profiles.sh round3"`).  Everything is written
+# repo root: `gpurun --timeout 1200 -- "KVQ_GIT_HEAD=$(git rev-parse HEAD) bash tools/make_profiles.sh round4"`; round 4 added part c).  Everything is written
 # under gpurun_out/<tag>/ ; copy what is to be kept into profiles/ afterwards (the script prints the cp lines).
 # PMC passes are separate runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes.
 set -u
-TAG=${1:-round3}
-PART=${2:-ab}            # a: traces, counters and the bench line; b: the other measurements (two gpurun calls of <= 20 min each)
+TAG=${1:-round4}
+PART=${2:-abc}           # a: traces, counters and the bench line; b: the other measurements; c (round 4): issue ledger, P4 counters, settings sweep, two-rank rehearsal (gpurun calls of <= 20 min each)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -57,6 +57,27 @@ step ubench
 ( cd tools/ubench && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o valu_rate valu_rate.hip 2>/dev/null && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o issue_rate issue_rate.hip 2>/dev/null
   timeout -k 10 120 ./valu_rate > $O/valu_rate.txt 2>&1 && timeout -k 10 120 ./issue_rate > $O/issue_rate.txt 2>&1 )
 fi
+if [[ $PART == *c* ]]; then
+cd $R
+step ledger; bash tools/r4_ledger.sh $TAG > /dev/null 2>&1
+step p4counters
+if [ -f kvarq_amd/abx/tally.so ]; then
+  cp kvarq_amd/libkvarq_hip.so /tmp/lib_keep.so; cp kvarq_amd/abx/tally.so kvarq_amd/libkvarq_hip.so
+  ( echo "what P4 eats (instrumented build with -DKVQ_TALLY, 2.5 M reads of the bench workload; tools/phase_stamps.py):"; KVQ_DBG=16 timeout -k 10 200 python3 tools/phase_stamps.py 2>&1 | grep "^P4" ) > $O/p4_counters.txt
+  cp /tmp/lib_keep.so kvarq_amd/libkvarq_hip.so
+fi
+step settings
+( echo "engine settings next to the product's (10 M x 150 bp, MTBC table; bench.py --maxerrors / --minoverlap; kvq_seed_k picks the seed length):"
+  for args in "--maxerrors 0" "--maxerrors 1" "--maxerrors 2" "--maxerrors 3" "--maxerrors 1 --minoverlap 20" "--maxerrors 3 --minoverlap 35"; do
+    timeout -k 10 300 python3 bench.py $args --no-cpu-baseline --no-end-to-end --steps 5 2> $O/cfg.err | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('%-34s step %.3f ms  kernel %.3f ms  roofline %.4f  %.2f G reads/s  %s' % (sys.argv[1], d['ms_per_step'], r['avg_launch_ms'], r['frac'], d['value']/1e9, d['config']['kernel_path']))" "$args"
+  done ) > $O/settings_sweep.txt 2>&1
+step tworanks
+# `python bench.py --gpus 2` by itself starts two ranks; on a one-GPU box they share the card and rendezvous over gloo (RCCL refuses two ranks on one device)
+( KVQ_BENCH_BACKEND=gloo timeout -k 10 400 python3 bench.py --gpus 2 --reads 2000000 --steps 5 --no-cpu-baseline --no-end-to-end > $O/bench_n2_gloo_rehearsal.json 2> $O/bench_n2.err; tail -2 $O/bench_n2.err >> $O/bench_n2_gloo_rehearsal.json ) 
+fi
 if [[ $PART == *a* ]]; then
 cd $R
 # the bench line last: it quotes the traffic file made above (same sources)
@@ -64,7 +85,7 @@ step bench;  cp $O/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json; timeout
 timeout -k 10 400 python3 bench.py --pipeline 1 --no-cpu-baseline --no-end-to-end > $O/bench_n1_pipeline1.json 2>> $O/bench.err
 fi
 step done
-for f in bench_n1.json kernel_agreement.txt bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt file_path.txt long_reads.txt scan_gaps.txt grid_sweep.txt dense_tables.txt host_ceiling.txt host_ceiling_flags.txt probe_ablation.txt kernel_time_by_size.txt time_by_occupancy.txt clock.txt valu_rate.txt issue_rate.txt; do
+for f in bench_n1.json kernel_agreement.txt bench_n1_pipeline1.json rocprofv3_kernel_stats_pipeline1.csv step_timeline_pipelined.txt rocprofv3_kernel_stats.csv pmc_traffic.json pmc_sq_counters.txt step_timeline.txt phase_stamps.txt step_host_times.txt pmc_phases.txt other_configs.txt file_rate.txt file_path.txt long_reads.txt scan_gaps.txt grid_sweep.txt dense_tables.txt host_ceiling.txt host_ceiling_flags.txt probe_ablation.txt kernel_time_by_size.txt time_by_occupancy.txt clock.txt valu_rate.txt issue_rate.txt issue_ledger.txt ledger_pmc.txt ledger_times.txt p4_counters.txt settings_sweep.txt bench_n2_gloo_rehearsal.json; do
   echo "cp gpurun_out/$TAG/$f profiles/${TAG}_$f"
 done
 [[ $PART == *a* ]] && cat $O/bench_n1.json
