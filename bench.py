@@ -99,6 +99,12 @@ def main():
                           'gpu_modules_loaded': [m for m in ('torch', 'kvarq_amd._lib') if m in sys.modules]}))
         return
 
+    # (RCCL and gloo print banners on stdout when communicators are made; the contract is ONE JSON line there: everything the
+    # setup prints goes to stderr instead -- file descriptor 1 is pointed at 2 until the line is due)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -384,6 +390,8 @@ def main():
         out['end_to_end'] = end_to_end(d_data, n, rb, seqs, cfg)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(g, seqs, cfg, L, rb, args.cpu_seconds)
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     print(json.dumps(out))
     sys.stdout.flush()
     if world > 1:
@@ -433,7 +441,9 @@ def spawn_ranks(n):
                 rc = rc or 124
             time.sleep(0.05)
     reader.join(10)
-    sys.stdout.write(b''.join(out0).decode())
+    lines = b''.join(out0).decode(errors='replace').splitlines()
+    for line in lines:                               # rank 0's JSON line to stdout, anything else it printed to stderr
+        (sys.stdout if line.startswith('{') else sys.stderr).write(line + '\n')
     sys.stdout.flush()
     return rc
 

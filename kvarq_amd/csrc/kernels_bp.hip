@@ -222,6 +222,7 @@ struct BpArgs {
     const uint4 *tiles; uint32_t *tile_report; unsigned int *tile_ctr;
     void *redo;                       // KvqRedo: where a read that floods its wave's queues is put for the exhaustive matcher
     unsigned int *fail;               // the batch's fail word (bit 1: such reads exist)
+    void *surv;                       // KvqSurvivors: work items that passed the 16-base test, verified behind the kernel (kvq_verify_survivors)
     uint32_t ntiles, tile_bytes, dbg, pad_, redo_cap, pad2_;
 };
 // Tiles are handed out by counters.  One counter for the whole launch is a ceiling by itself: a word in
@@ -957,6 +958,93 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     if (tid == 0) {
         if (S.longest_p1) atomicMax(&ctr[KVQ_CTR_LONGEST_], (unsigned long long)S.longest_p1);
         if (S.records) atomicAdd(&ctr[KVQ_CTR_RECORDS_], (unsigned long long)S.records);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kvq_verify_survivors: the byte-exact part for what passed the scan kernel's 16-base test, a lane per work item (round 4)
+// ---------------------------------------------------------------------------
+// The rules are bp_verify_rest's (which loops of the reference visit the diagonal, the mismatch count over the whole overlap, the
+// canonical discoverer among the seeds that find the diagonal, the emit); the read's bases come from the batch's text in global
+// memory instead of the tile's planes, which are gone by now: a seed is live when the K codes (byte >> 1) & 3 of the read equal the
+// sequence's -- the very codes the planes held.
+__device__ __forceinline__ bool seed_live_text(GlbBytes read, GlbBytes seq, int K, int rl, int rp, int seql, int sq)
+{
+    if (rp < 0 || rp + K > rl || sq < 0 || sq + K > seql) return false;
+    uint32_t diff = 0;
+    for (int t = 0; t < K; t++) diff |= ((uint32_t)read[rp + t] ^ (uint32_t)seq[sq + t]) & 6u;
+    return diff == 0u;
+}
+extern "C" __global__ void __launch_bounds__(256)
+kvq_verify_survivors(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, const void *surv_, const unsigned int *__restrict__ fail,
+                     int K, int stride, int pitch)
+{
+    const KvqSurvivors Sv(const_cast<void *>(surv_));
+    if (fail && (*fail & 1u)) return;                          // (the batch is redone as a whole: its hits are rolled back anyway)
+    const uint32_t n = *Sv.count < KVQ_SURV_CAP ? *Sv.count : KVQ_SURV_CAP;
+    const int me = P.maxerrors, mo = P.minoverlap;
+    const uint32_t step = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += step) {
+        const uint32_t i = base + (threadIdx.x & 63u);
+        bool hitAB = false, hitC = false;
+        int s = 0, rl = 0, lenAB = 0, lenC = 0, sposAB = 0, sposC = 0; uint32_t keyAB = 0, keyC = 0; int64_t fpos = 0;
+        if (i < n) {
+            const KvqSurvivor v = Sv.item[i];
+            rl = (int)v.rl; const int p = (int)v.p; const uint32_t kind = v.kind;
+            fpos = fpos_base + (int64_t)v.boff;
+            const int q = (int)(v.en & 4095u);
+            s = (int)((v.en >> 12) & 0xFFFFFu);
+            const uint32_t toff = (uint32_t)((v.en >> 32) & 0xFFFFFu);
+            const int seql = (int)(v.en >> 52);
+            const GlbBytes read = (GlbBytes)data + v.boff, seq = (GlbBytes)P.tab + toff;
+            const int d = q - p;                             // sequence index = read index + d
+            const int a = d < 0 ? -d : 0;
+            const int L = (rl < seql - d ? rl : seql - d) - a;
+            bool canAB = false, canC = false;
+            const bool guard = rl > mo && seql > mo;
+            if (d < 0) {
+                const int ii = -d;
+                if (ii <= rl - seql) { canC = true; lenC = seql; sposC = -ii; keyC = (2u << 30) | (uint32_t)ii; }              // 1147
+                else if (guard && ii <= rl - mo) { canAB = true; lenAB = rl - ii; sposAB = -ii; keyAB = (0u << 30) | (uint32_t)(rl - mo - ii); }   // 1116
+            } else if (d == 0) {
+                canC = true; lenC = rl > seql ? seql : rl; sposC = 0; keyC = 2u << 30;                                         // 1147 / 1163
+            } else {
+                const int ii = d;
+                if (guard && ii <= seql - mo && ii >= seql - rl) { canAB = true; lenAB = seql - ii; sposAB = ii; keyAB = (1u << 30) | (uint32_t)(seql - mo - ii); }   // 1130
+                if (rl <= seql && ii <= seql - rl) { canC = true; lenC = rl; sposC = ii; keyC = (2u << 30) | (uint32_t)ii; }       // 1163
+            }
+            if ((canAB || canC) && L > 0) {
+                int mism = 0, j = 0;
+                const GlbBytes x = read + a, y = seq + (a + d);
+                for (; j + 16 <= L && mism <= me; j += 16) {
+                    typedef u32x4_t __attribute__((aligned(1))) u32x4_any;
+                    const u32x4_t xv = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_any *>(x + j);
+                    const u32x4_t yv = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_any *>(y + j);
+                    mism += diff_bytes(xv.x, yv.x) + diff_bytes(xv.y, yv.y) + diff_bytes(xv.z, yv.z) + diff_bytes(xv.w, yv.w);
+                }
+                for (; j + 4 <= L && mism <= me; j += 4) mism += diff_bytes(glb_u32(x + j), glb_u32(y + j));
+                for (; j < L && mism <= me; j++) mism += (x[j] != y[j]);
+                if (mism <= me) {
+                    // canonical discoverer: no live seed earlier in the order [ALL-index read blocks by position] then [ANCHOR blocks by number]
+                    bool earlier = false;
+                    for (int jj = 0; jj <= me && !earlier; jj++) {
+                        const int ph = jj * K, pt = rl - (jj + 1) * K;
+                        if (ph + K <= rl && (kind == 0u || ph < p)) earlier = seed_live_text(read, seq, K, rl, ph, seql, ph + d);
+                        if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live_text(read, seq, K, rl, pt, seql, pt + d);
+                    }
+                    if (kind == 0u) {
+                        for (int jj = 0; jj <= me && !earlier; jj++)
+                            for (int sft = 0; sft < stride && !earlier; sft++) {
+                                const int o = jj * pitch + sft;
+                                if (o < q && ((o - d) & (stride - 1)) == 0) earlier = seed_live_text(read, seq, K, rl, o - d, seql, o);
+                            }
+                    }
+                    if (!earlier) { hitAB = canAB; hitC = canC; }
+                }
+            }
+        }
+        kvq_emit(P, hitAB, fpos, s, sposAB, lenAB, rl, keyAB);
+        kvq_emit(P, hitC, fpos, s, sposC, lenC, rl, keyC);
     }
 }
 

@@ -366,10 +366,12 @@ kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, co
 
 // one thread per chunk: per-tile table {chunk begin, chunk end, tile number inside the chunk, chunk}
 extern "C" __global__ void __launch_bounds__(256)
-kvq_expand_tiles(uint32_t nchunks, const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ tile_first, uint4 *__restrict__ tile_tab, unsigned int *__restrict__ redo_count)
+kvq_expand_tiles(uint32_t nchunks, const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ tile_first, uint4 *__restrict__ tile_tab, unsigned int *__restrict__ redo_count,
+                 unsigned int *__restrict__ surv_count)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && redo_count) { redo_count[0] = 0; redo_count[1] = 0; }      // (records that skipped tiles leave, and the long ones among them, are counted afresh for this launch)
+    if (c == 0 && surv_count) surv_count[0] = 0;                             // (and so are the scan kernel's survivors)
     if (c >= nchunks) return;
     const uint32_t a = chunk_off[c], b = chunk_off[c + 1], g0 = tile_first[c];
     for (uint32_t g = g0; g < tile_first[c + 1]; g++) tile_tab[g] = make_uint4(a, b, g - g0, c);

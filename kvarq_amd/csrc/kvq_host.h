@@ -74,6 +74,18 @@ struct Batch {
 
 struct kvq_comm;
 #define KVQ_REDO_CAP 16384u            // records that the skipped tiles of one launch may leave (beyond: the batch is redone as a whole)
+// The scan kernel's survivors (round 4): a work item that passed the 16-base test -- a true hit as a rule, 0.02 per read -- is put on
+// this list instead of being verified where it was found; kvq_verify_survivors, right behind the scan kernel, does the byte-exact
+// part for all of them at once (a lane each).  Where it was found it cost its wave some twenty dependent trips to memory, and the
+// other seven waves of the tile the wait for it: 6 % of the kernel's time for 0.003 hits per read.  A full list costs nothing but
+// speed: the items that do not fit are verified in place, as before.
+struct KvqSurvivor { uint32_t boff; uint16_t rl, p; uint64_t en; uint32_t kind, pad; };      // batch offset of the trimmed read, its length, read position of the seed, index entry, which index
+#define KVQ_SURV_CAP (1u << 20)
+struct KvqSurvivors {
+    unsigned int *count; KvqSurvivor *item;
+    static size_t bytes() { return 256 + (size_t)KVQ_SURV_CAP * sizeof(KvqSurvivor); }
+    __host__ __device__ explicit KvqSurvivors(void *p) { count = (unsigned int *)p; item = (KvqSurvivor *)((char *)p + 256); }
+};
 struct KvqRedo {                      // where the pieces lie inside kvq_scan::d_redo
     unsigned int *count; uint32_t *nl4, *rec_start, *read_off; int32_t *read_len;
     static size_t bytes() { return 256 + (size_t)KVQ_REDO_CAP * (16 + 4 + 4 + 4); }
@@ -99,6 +111,7 @@ struct kvq_scan {
     // per-batch scratch
     uint32_t cus = 0;                  // compute units of the scan's device (asked once)
     bool seen_skips = false;           // a tile of this scan object has left records to the redo before (kept across resets: sizes the redo's launches)
+    DevBuf d_surv;                     // what passed the scan kernel's 16-base test, for kvq_verify_survivors (KvqSurvivors)
     DevBuf d_redo;                     // the redo of skipped tiles (KvqRedo: count, newline quadruples, record starts, trimmed reads)
     DevBuf d_skipped, d_chunk_off, d_seg_base, d_seg_cnt, d_chunk_nrec, d_rec_base, d_nl4, d_rec_start, d_read_off, d_read_len;
     // hit arena

@@ -80,6 +80,8 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         static const uint32_t stagger = (uint32_t)(getenv("KVQ_STAGGER") ? atoi(getenv("KVQ_STAGGER")) : 0);
         a.ntiles = (uint32_t)nt; a.tile_bytes = TILE; a.dbg = dbg; a.pad_ = stagger;
         a.redo = s->d_redo.p; a.redo_cap = KVQ_REDO_CAP - KVQ_LONG_CAP; a.fail = s->cur_fail;
+        static const bool surv_off = getenv("KVQ_SURVIVORS") && getenv("KVQ_SURVIVORS")[0] == '0';      // (tests: 0 = every work item is verified where it is found)
+        a.surv = surv_off ? nullptr : s->d_surv.p;
         memcpy(s->pool.h + first_at + first_b, &a, sizeof(a));
     }
     {
@@ -91,7 +93,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     KVQ_HIP(hipMemcpyAsync(s->pool.d + s->cur_co_at, s->pool.h + s->cur_co_at, ctr_at + 4 * BP_SHARDS * BP_SHARD_STRIDE - s->cur_co_at,
                            hipMemcpyHostToDevice, s->stream));
     hipLaunchKernelGGL(kvq_expand_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks, d_chunk_off, d_first, reinterpret_cast<uint4 *>(d_tchunk),
-                       s->d_redo.p ? KvqRedo(s->d_redo.p).count : (unsigned int *)nullptr);
+                       s->d_redo.p ? KvqRedo(s->d_redo.p).count : (unsigned int *)nullptr, s->d_surv.p ? KvqSurvivors(s->d_surv.p).count : (unsigned int *)nullptr);
 
     // the scan kernel alone between the pair of events its time is read from (bench.py's roofline figure; rocprofv3 --kernel-trace
     // gives the same duration): the table upload, kvq_expand_tiles and kvq_validate_tiles stand outside
@@ -142,7 +144,11 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         hipLaunchKernelGGL(kern, dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
     }
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
-    { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }              // (kvq_validate_tiles and what follows run beside the next scan)
+    { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }
+    // what passed the scan kernel's 16-base test (0.02 work items per read of the bench workload), byte-exact: a lane each, fixed grid, count on the device
+    if (s->d_surv.p)
+        hipLaunchKernelGGL(kvq_verify_survivors, dim3(64), dim3(256), 0, s->stream, P, d_data, fpos_base, (const void *)s->d_surv.p, (const unsigned int *)s->cur_fail,
+                           ix->k, ix->stride, ix->pitch);              // (kvq_validate_tiles and what follows run beside the next scan)
     if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                        d_first, d_report, s->cur_fail, reinterpret_cast<KvqSkippedTile *>(s->pool.d + skip_at), d_chunk_off, TILE);

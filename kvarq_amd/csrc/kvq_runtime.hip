@@ -379,6 +379,8 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     s->d_fail = (unsigned int *)((char *)s->d_small.p + SMALL_FAIL);
     s->d_stage_ctr = (unsigned long long *)((char *)s->d_small.p + SMALL_STAGE);
     if (ensure_arena(s, 1u << 20, 64ull << 20) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
+    if (s->d_surv.ensure(KvqSurvivors::bytes()) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
+    if (hipMemsetAsync(s->d_surv.p, 0, 256, s->stream) != hipSuccess) { kvq_scan_destroy(s); return nullptr; }
     if (s->d_redo.ensure(KvqRedo::bytes()) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     if (hipMemsetAsync(s->d_redo.p, 0, 256, s->stream) != hipSuccess) { kvq_scan_destroy(s); return nullptr; }      // (the block comes from the cache as it was left: the redo's two counts start at zero)
     s->pin_cap = (size_t)t->ctr_len * 8 + (4u << 20);
@@ -452,7 +454,7 @@ extern "C" void kvq_scan_destroy(kvq_scan *s)
     for (int i = 0; i < 2; i++) if (s->ev_copy[i]) (void)hipEventDestroy(s->ev_copy[i]);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     if (s->ev_chain) (void)hipEventDestroy(s->ev_chain);
-    DevBuf *bufs[] = { &s->d_redo, &s->d_ctr_all, &s->d_gather_cnt, &s->d_gather_res, &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_order, &s->d_finish, &s->d_covdiff, &s->d_skipped, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
+    DevBuf *bufs[] = { &s->d_surv, &s->d_redo, &s->d_ctr_all, &s->d_gather_cnt, &s->d_gather_res, &s->d_sort_tmp, &s->d_sorted, &s->d_result, &s->d_order, &s->d_finish, &s->d_covdiff, &s->d_skipped, &s->d_chunk_off, &s->d_seg_base, &s->d_seg_cnt, &s->d_chunk_nrec, &s->d_rec_base, &s->d_nl4,
                        &s->d_rec_start, &s->d_read_off, &s->d_read_len, &s->d_arena, &s->d_blob, &s->d_small, &s->d_stage, &s->d_stage_b };
     for (DevBuf *b : bufs) b->release();
     s->pool.release();
