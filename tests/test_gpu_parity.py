@@ -811,7 +811,7 @@ def test_a_read_that_floods_its_waves_queues_is_matched_on_its_own():
         s.reset()
         s.scan_device(d.ptr, text.nbytes, co)
         r = s.finish()
-        if os.environ.get('KVQ_DENSE') == '1':                      # (the draining kernels take such a read themselves: nothing is left for the redo)
+        if os.environ.get('KVQ_DENSE') == '1' or os.environ.get('KVQ_K') in ('5', '6', '7'):   # (the draining kernels -- always, for seeds shorter than 8 -- take such a read themselves: nothing is left for the redo)
             assert r['path'] == dict(seeded=True, exhaustive=False, rescanned=False, tiles_rescanned=False), r['path']
         else:
             assert r['path'] == REDO_PATH, r['path']               # (records behind the scan, not the batch again)
