@@ -55,6 +55,7 @@ struct BpLds {
     __attribute__((aligned(16))) uint8_t head[BP_HEAD];   // the first bytes of the window as text (P2 looks at line starts there)
     __attribute__((aligned(16))) uint32_t wtot[ST_WAVES];
     uint32_t longest_p1, records, fallback, n_owned, next_tile, first_tile, p2_jn;
+    uint32_t sv_at[ST_WAVES], sv_end[ST_WAVES];      // each wave's chunk of the survivors' list: next free slot, end
 };
 static_assert(sizeof(BpLds) <= 40 * 1024, "four workgroups per CU: at most 40 KB of LDS each");
 static_assert(offsetof(BpLds, cdp) == 0, "cdp[] first");
@@ -346,7 +347,7 @@ __device__ __forceinline__ void bp_runs64(uint64_t m, int n, uint32_t dbg, int &
 // bitmaps' occupancy: seeds shorter than 8, the MTBC table x 8 and beyond): the queues are drained as they fill instead of the stretch being
 // halved and filtered again
 template <int SS, int LG, bool STAMPS, bool DIAG = STAMPS, int KK = 8, bool DENSE = (KK < 8)>
-__global__ void __launch_bounds__(ST_THREADS, BP_OCC)
+__global__ void __launch_bounds__(ST_THREADS, DENSE ? 6 : BP_OCC)     // (the draining kernels: 80 registers and three workgroups per CU -- at 64 they spill to scratch, which costs them far more than the waves)
 kvq_scan_bp(const BpArgs *__restrict__ A_)
 {
     __shared__ __align__(16) BpLds S;
@@ -387,6 +388,7 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
     }
     for (int i = tid; i < KVQ_RL_BINS / 2; i += ST_THREADS) S.hist[i] = 0;
     if (tid == 0) { S.longest_p1 = 0; S.records = 0; S.fallback = 0; }
+    if (tid < (int)ST_WAVES) { S.sv_at[tid] = 0; S.sv_end[tid] = 0; }
     if (tid < 8) { S.cdp[BP_WIN / 16 + tid] = 0; S.gdp[BP_WIN / 32 + tid] = 0; }    // slack behind the planes
 
     static_assert(ST_ROUNDS * 16u == ST_BLK, "one scan block per thread");
@@ -844,39 +846,31 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
                     // when a queue overflows -- up to six times per stretch with the MTBC table x 8 ----
                     uint32_t hA = 0, hpos = 0, tpos = 0; bool hh = false, th = false;
                     int ee = e0, xt = (int)G;
-                    auto gen_next = [&]() -> bool {
-                        if (__any(ee < e1)) {
-                            {
-                                const bool act = ee < e1;
-                                uint32_t hA_;
-                                {
-#include "kernels_bp_lookup.inc"
-                                    hA_ = hA;
-                                }
-                                const int nv = act ? (e1 - ee < NR ? e1 - ee : NR) : 0;
-                                hA = hA_ & ((1u << nv) - 1u);
-                            }
-                            if (first) { hh = hhit; th = thit; hpos = gl * KK; tpos = (uint32_t)(rl - ((int)gl + 1) * KK); first = false; }
-                            ee += NR;
-                            return true;
-                        }
-                        if (xt <= me_) {                                        // groups narrower than e + 1 lanes: the remaining head and tail blocks
-                            const int jj = xt + (int)gl;
-                            hpos = (uint32_t)(jj * KK); tpos = (uint32_t)(rl - (jj + 1) * KK);
-                            hh = fixed_block((int)hpos, head_ok(jj)); th = fixed_block((int)tpos, tail_ok(jj));
-                            xt += (int)G;
-                            return true;
-                        }
-                        return false;
-                    };
                     int ee_of_hA = e0;                                          // the round the pending anchor bits belong to
                     bool done = false;
                     while (!done) {
                         bool full = false;
                         while (!full) {
                             if (!__any(hA != 0u || hh || th)) {
+                                // nothing pending: the next round of lookups (spelled out here, not a lambda: what a lambda captures by reference lives in scratch memory)
                                 ee_of_hA = ee;
-                                if (!gen_next()) { done = true; break; }
+                                if (__any(ee < e1)) {
+                                    const bool act = ee < e1;
+                                    uint32_t hA_;
+                                    {
+#include "kernels_bp_lookup.inc"
+                                        hA_ = hA;
+                                    }
+                                    const int nv = act ? (e1 - ee < NR ? e1 - ee : NR) : 0;
+                                    hA = hA_ & ((1u << nv) - 1u);
+                                    if (first) { hh = hhit; th = thit; hpos = gl * KK; tpos = (uint32_t)(rl - ((int)gl + 1) * KK); first = false; }
+                                    ee += NR;
+                                } else if (xt <= me_) {                             // groups narrower than e + 1 lanes: the remaining head and tail blocks
+                                    const int jj = xt + (int)gl;
+                                    hpos = (uint32_t)(jj * KK); tpos = (uint32_t)(rl - (jj + 1) * KK);
+                                    hh = fixed_block((int)hpos, head_ok(jj)); th = fixed_block((int)tpos, tail_ok(jj));
+                                    xt += (int)G;
+                                } else { done = true; break; }
                                 continue;
                             }
                             const uint32_t c = (uint32_t)__popc(hA) + (hh ? 1u : 0u) + (th ? 1u : 0u);
@@ -934,6 +928,11 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
 
     unsigned long long rt_loop = 0;
     if constexpr (STAMPS) rt_loop = __builtin_amdgcn_s_memrealtime();
+    {
+        // what is left of the wave's chunk of the survivors' list is marked dead (read length 0: kvq_verify_survivors skips it)
+        const uint32_t at = S.sv_at[wave], end = S.sv_end[wave];
+        if (at + (uint32_t)lane < end) KvqSurvivors(bp_args(A_)->surv).item[at + (uint32_t)lane].rl = 0;
+    }
     atomicMax(&S.longest_p1, my_longest);
     __syncthreads();
     unsigned long long *const ctr = (bp_args(A_)->P.ctr + (size_t)(blockIdx.x % KVQ_STAGE_COPIES) * KVQ_STAGE_SLOTS);
@@ -990,7 +989,7 @@ kvq_verify_survivors(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos
         int s = 0, rl = 0, lenAB = 0, lenC = 0, sposAB = 0, sposC = 0; uint32_t keyAB = 0, keyC = 0; int64_t fpos = 0;
         if (i < n) {
             const KvqSurvivor v = Sv.item[i];
-            rl = (int)v.rl; const int p = (int)v.p; const uint32_t kind = v.kind;
+            rl = (int)v.rl; const int p = (int)v.p; const uint32_t kind = v.kind;      // (rl 0: a slot of some wave's chunk that was never filled)
             fpos = fpos_base + (int64_t)v.boff;
             const int q = (int)(v.en & 4095u);
             s = (int)((v.en >> 12) & 0xFFFFFu);
@@ -1013,7 +1012,7 @@ kvq_verify_survivors(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos
                 if (guard && ii <= seql - mo && ii >= seql - rl) { canAB = true; lenAB = seql - ii; sposAB = ii; keyAB = (1u << 30) | (uint32_t)(seql - mo - ii); }   // 1130
                 if (rl <= seql && ii <= seql - rl) { canC = true; lenC = rl; sposC = ii; keyC = (2u << 30) | (uint32_t)ii; }       // 1163
             }
-            if ((canAB || canC) && L > 0) {
+            if ((canAB || canC) && L > 0 && rl > 0) {
                 int mism = 0, j = 0;
                 const GlbBytes x = read + a, y = seq + (a + d);
                 for (; j + 16 <= L && mism <= me; j += 16) {

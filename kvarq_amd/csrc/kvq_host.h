@@ -80,7 +80,9 @@ struct kvq_comm;
 // other seven waves of the tile the wait for it: 6 % of the kernel's time for 0.003 hits per read.  A full list costs nothing but
 // speed: the items that do not fit are verified in place, as before.
 struct KvqSurvivor { uint32_t boff; uint16_t rl, p; uint64_t en; uint32_t kind, pad; };      // batch offset of the trimmed read, its length, read position of the seed, index entry, which index
-#define KVQ_SURV_CAP (1u << 20)
+#define KVQ_SURV_CAP (1u << 22)
+#define KVQ_SURV_CHUNK 16u             // a wave takes the list's slots a chunk at a time (one atomic on the list's counter per chunk, not per survivor:
+                                       // a word in memory takes ~88 atomics per microsecond, hit-dense input would queue up on it)
 struct KvqSurvivors {
     unsigned int *count; KvqSurvivor *item;
     static size_t bytes() { return 256 + (size_t)KVQ_SURV_CAP * sizeof(KvqSurvivor); }
