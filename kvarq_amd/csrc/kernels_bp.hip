@@ -347,7 +347,7 @@ __device__ __forceinline__ void bp_runs64(uint64_t m, int n, uint32_t dbg, int &
 // bitmaps' occupancy: seeds shorter than 8, the MTBC table x 8 and beyond): the queues are drained as they fill instead of the stretch being
 // halved and filtered again
 template <int SS, int LG, bool STAMPS, bool DIAG = STAMPS, int KK = 8, bool DENSE = (KK < 8)>
-__global__ void __launch_bounds__(ST_THREADS, DENSE ? 6 : BP_OCC)     // (the draining kernels: 80 registers and three workgroups per CU -- at 64 they spill to scratch, which costs them far more than the waves)
+__global__ void __launch_bounds__(ST_THREADS, DENSE ? 8 : BP_OCC)
 kvq_scan_bp(const BpArgs *__restrict__ A_)
 {
     __shared__ __align__(16) BpLds S;
