@@ -970,8 +970,15 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
 __device__ __forceinline__ bool seed_live_text(GlbBytes read, GlbBytes seq, int K, int rl, int rp, int seql, int sq)
 {
     if (rp < 0 || rp + K > rl || sq < 0 || sq + K > seql) return false;
-    uint32_t diff = 0;
-    for (int t = 0; t < K; t++) diff |= ((uint32_t)read[rp + t] ^ (uint32_t)seq[sq + t]) & 6u;
+    // K <= 8 bases as two (unaligned) 4-byte words a side; bytes behind the K-th are masked off (they exist: a newline follows the read,
+    // the table has 64 bytes of slack)
+    const uint32_t x0 = glb_u32(read + rp), y0 = glb_u32(seq + sq);
+    uint32_t diff = (x0 ^ y0) & 0x06060606u;
+    if (K > 4) {
+        const uint32_t x1 = glb_u32(read + rp + 4), y1 = glb_u32(seq + sq + 4);
+        const uint32_t m1 = K >= 8 ? 0x06060606u : (0x06060606u & ((1u << (8 * (K - 4))) - 1u));
+        diff |= (x1 ^ y1) & m1;
+    } else diff &= (1u << (8 * K)) - 1u;
     return diff == 0u;
 }
 extern "C" __global__ void __launch_bounds__(256)
@@ -1013,32 +1020,34 @@ kvq_verify_survivors(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos
                 if (rl <= seql && ii <= seql - rl) { canC = true; lenC = rl; sposC = ii; keyC = (2u << 30) | (uint32_t)ii; }       // 1163
             }
             if ((canAB || canC) && L > 0 && rl > 0) {
-                int mism = 0, j = 0;
-                const GlbBytes x = read + a, y = seq + (a + d);
-                for (; j + 16 <= L && mism <= me; j += 16) {
-                    typedef u32x4_t __attribute__((aligned(1))) u32x4_any;
-                    const u32x4_t xv = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_any *>(x + j);
-                    const u32x4_t yv = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_any *>(y + j);
-                    mism += diff_bytes(xv.x, yv.x) + diff_bytes(xv.y, yv.y) + diff_bytes(xv.z, yv.z) + diff_bytes(xv.w, yv.w);
+                // canonical discoverer FIRST: no live seed earlier in the order [ALL-index read blocks by position] then [ANCHOR blocks by
+                // number].  A true hit's diagonal is met by half a dozen seeds, so five survivors in six end here, after a load or two,
+                // and only the one that will emit compares the whole overlap (the in-place form counts first: it has the bytes at hand).
+                bool earlier = false;
+                for (int jj = 0; jj <= me && !earlier; jj++) {
+                    const int ph = jj * K, pt = rl - (jj + 1) * K;
+                    if (ph + K <= rl && (kind == 0u || ph < p)) earlier = seed_live_text(read, seq, K, rl, ph, seql, ph + d);
+                    if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live_text(read, seq, K, rl, pt, seql, pt + d);
                 }
-                for (; j + 4 <= L && mism <= me; j += 4) mism += diff_bytes(glb_u32(x + j), glb_u32(y + j));
-                for (; j < L && mism <= me; j++) mism += (x[j] != y[j]);
-                if (mism <= me) {
-                    // canonical discoverer: no live seed earlier in the order [ALL-index read blocks by position] then [ANCHOR blocks by number]
-                    bool earlier = false;
-                    for (int jj = 0; jj <= me && !earlier; jj++) {
-                        const int ph = jj * K, pt = rl - (jj + 1) * K;
-                        if (ph + K <= rl && (kind == 0u || ph < p)) earlier = seed_live_text(read, seq, K, rl, ph, seql, ph + d);
-                        if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live_text(read, seq, K, rl, pt, seql, pt + d);
+                if (kind == 0u) {
+                    for (int jj = 0; jj <= me && !earlier; jj++)
+                        for (int sft = 0; sft < stride && !earlier; sft++) {
+                            const int o = jj * pitch + sft;
+                            if (o < q && ((o - d) & (stride - 1)) == 0) earlier = seed_live_text(read, seq, K, rl, o - d, seql, o);
+                        }
+                }
+                if (!earlier) {
+                    int mism = 0, j = 0;
+                    const GlbBytes x = read + a, y = seq + (a + d);
+                    for (; j + 16 <= L && mism <= me; j += 16) {
+                        typedef u32x4_t __attribute__((aligned(1))) u32x4_any;
+                        const u32x4_t xv = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_any *>(x + j);
+                        const u32x4_t yv = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_any *>(y + j);
+                        mism += diff_bytes(xv.x, yv.x) + diff_bytes(xv.y, yv.y) + diff_bytes(xv.z, yv.z) + diff_bytes(xv.w, yv.w);
                     }
-                    if (kind == 0u) {
-                        for (int jj = 0; jj <= me && !earlier; jj++)
-                            for (int sft = 0; sft < stride && !earlier; sft++) {
-                                const int o = jj * pitch + sft;
-                                if (o < q && ((o - d) & (stride - 1)) == 0) earlier = seed_live_text(read, seq, K, rl, o - d, seql, o);
-                            }
-                    }
-                    if (!earlier) { hitAB = canAB; hitC = canC; }
+                    for (; j + 4 <= L && mism <= me; j += 4) mism += diff_bytes(glb_u32(x + j), glb_u32(y + j));
+                    for (; j < L && mism <= me; j++) mism += (x[j] != y[j]);
+                    if (mism <= me) { hitAB = canAB; hitC = canC; }
                 }
             }
         }

@@ -147,7 +147,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
     { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }
     // what passed the scan kernel's 16-base test (0.02 work items per read of the bench workload), byte-exact: a lane each, fixed grid, count on the device
     if (s->d_surv.p)
-        hipLaunchKernelGGL(kvq_verify_survivors, dim3(128), dim3(256), 0, s->stream, P, d_data, fpos_base, (const void *)s->d_surv.p, (const unsigned int *)s->cur_fail,
+        hipLaunchKernelGGL(kvq_verify_survivors, dim3(256), dim3(256), 0, s->stream, P, d_data, fpos_base, (const void *)s->d_surv.p, (const unsigned int *)s->cur_fail,
                            ix->k, ix->stride, ix->pitch);              // (kvq_validate_tiles and what follows run beside the next scan)
     if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,

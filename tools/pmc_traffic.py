@@ -10,7 +10,7 @@ gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts half of 
 import csv, glob, json, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-def per_launch(root, counter, sub='kvq_scan_'):
+def per_launch(root, counter, sub='kvq_scan_bp'):
     acc = {}
     for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
         with open(f) as fh:
@@ -30,7 +30,7 @@ def main():
         except Exception:
             head = None                          # (the source hash is what ties the file to the code)
     f = per_launch(fdir, 'FETCH_SIZE'); w = per_launch(wdir, 'WRITE_SIZE')
-    steps = 3                                    # --steps 2 --warmup 1
+    steps = 3 + 5                                # --steps 2 --warmup 1, and the five steps bench.py runs one at a time behind them for `all_kernels_ms_per_step` (round 4)
     launches_per_step = len(f) // steps
     fm = sum(f) / len(f); wm = sum(w) / len(w)
     alg = reads * rb / launches_per_step
@@ -41,7 +41,7 @@ def main():
         'source_sha256': bench.source_sha256(), 'git_head': head,
         'note': 'gfx950: FETCH_SIZE counts 1/2 of the bytes of a 16-B-per-lane streaming read (MI355X_MICROARCH.md, HBM section), '
                 'so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact. Per-launch values are the mean over the launches of the run. '
-                'The text itself is streamed once (1.005 x the algorithmic bytes with every tile stopped behind the front end, profiles/round2_fetch_by_phase.txt); the rest are the two single-byte probes per record, the \'@\' and the \'+\' (workhorse.c:1037-1048), two in three of which miss L2 and count a whole line each (profiles/round3_probe_ablation.txt: without them 1.02 x, and 2.3 % less kernel time).',
+                'The text itself is streamed once (1.005 x the algorithmic bytes with every tile stopped behind the front end, profiles/round2_fetch_by_phase.txt); the rest are the two single-byte probes per record, the \'@\' and the \'+\' (workhorse.c:1037-1048), two in three of which miss L2 and count a whole line each (profiles/round3_probe_ablation.txt: without them 1.02 x; profiles/round4_probe_ablation.txt: the time of the kernel is the same with and without them).',
         'FETCH_SIZE_KB_per_launch_raw': f, 'FETCH_SIZE_KB_mean': fm,
         'WRITE_SIZE_KB_per_launch_raw': w, 'WRITE_SIZE_KB_mean': wm,
         'algorithmic_bytes_per_launch': alg,
