@@ -987,7 +987,7 @@ kvq_verify_survivors(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos
 {
     const KvqSurvivors Sv(const_cast<void *>(surv_));
     if (fail && (*fail & 1u)) return;                          // (the batch is redone as a whole: its hits are rolled back anyway)
-    const uint32_t n = *Sv.count < KVQ_SURV_CAP ? *Sv.count : KVQ_SURV_CAP;
+    const uint32_t n = Sv.count[0] < Sv.count[1] ? Sv.count[0] : Sv.count[1];      // (slots handed out, the list's size)
     const int me = P.maxerrors, mo = P.minoverlap;
     const uint32_t step = gridDim.x * blockDim.x;
     for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += step) {

@@ -380,7 +380,13 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
     s->d_stage_ctr = (unsigned long long *)((char *)s->d_small.p + SMALL_STAGE);
     if (ensure_arena(s, 1u << 20, 64ull << 20) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     if (s->d_surv.ensure(KvqSurvivors::bytes()) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
-    if (hipMemsetAsync(s->d_surv.p, 0, 256, s->stream) != hipSuccess) { kvq_scan_destroy(s); return nullptr; }
+    {
+        // header: slots handed out, the list's size (KVQ_SURV_CAP=<slots> shrinks it for the tests: a full list costs speed, never results)
+        unsigned int hdr[64] = { 0 };
+        hdr[1] = KVQ_SURV_CAP;
+        if (const char *e = getenv("KVQ_SURV_CAP")) { const long v = atol(e); if (v >= 0 && v < (long)KVQ_SURV_CAP) hdr[1] = (unsigned int)v; }
+        if (hipMemcpyAsync(s->d_surv.p, hdr, 256, hipMemcpyHostToDevice, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) { kvq_scan_destroy(s); return nullptr; }
+    }
     if (s->d_redo.ensure(KvqRedo::bytes()) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }
     if (hipMemsetAsync(s->d_redo.p, 0, 256, s->stream) != hipSuccess) { kvq_scan_destroy(s); return nullptr; }      // (the block comes from the cache as it was left: the redo's two counts start at zero)
     s->pin_cap = (size_t)t->ctr_len * 8 + (4u << 20);

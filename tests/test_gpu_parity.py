@@ -674,6 +674,30 @@ def test_replay_of_kept_host_batches_neither_copies_them_again_nor_forgets_them(
     s.close(); s2.close(); t.close(); t2.close(); d.free()
 
 
+@pytest.mark.parametrize('cap', [0, 16, 100, 5000])
+def test_a_full_survivors_list_costs_speed_never_results(cap, monkeypatch):
+    """Work items that pass the scan kernel's 16-base test go to a list that kvq_verify_survivors empties behind the kernel, a wave taking
+    its slots sixteen at a time; what a full list has no room for is verified in place.  With the list cut down to nothing, to one chunk,
+    to a few, to less than the input needs (KVQ_SURV_CAP: slots), the hits, their order and every counter stay the oracle's."""
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g))
+    # reads sampled from the templates' own loci: every read is a true hit on several diagonals (a few thousand survivors)
+    host = synth.reads(g, 0, 30000, 150)
+    want = O.scan_memory(host, seqs, fold=True, nthreads=4, **cases.PRODUCT)
+    monkeypatch.setenv('KVQ_SURV_CAP', str(cap))
+    t = scan.Table(seqs, **cases.PRODUCT)
+    s = scan.Scanner(t)
+    d = scan.DeviceBuffer(host.nbytes); d.upload(host)
+    for rep in range(2):                                               # (the list's counter starts afresh with every launch)
+        s.reset()
+        s.scan_device(d.ptr, host.nbytes, scan.chunk_offsets(host))
+        r = s.finish()
+        assert len(want['hits']) > 50 and tuple(r['hits']) == tuple(want['hits']) and r['hitseqs'] == want['hitseqs']
+        assert r['stats']['nseqhits'] == want['stats']['nseqhits'] and r['stats']['nseqbasehits'] == want['stats']['nseqbasehits']
+        assert r['coverage'].tolist() == want['coverage'] and r['mutations'].tolist() == want['mutations']
+    s.close(); t.close(); d.free()
+
+
 def test_one_long_record_costs_its_tile_not_the_batch():
     """300 k ordinary reads with ONE 5 kB record in their middle: the record outgrows the look-ahead of the tile
     that owns it; only that tile's records go through the exhaustive kernels (path: tiles_rescanned, not
