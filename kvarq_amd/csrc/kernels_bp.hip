@@ -224,7 +224,8 @@ struct BpArgs {
     void *redo;                       // KvqRedo: where a read that floods its wave's queues is put for the exhaustive matcher
     unsigned int *fail;               // the batch's fail word (bit 1: such reads exist)
     void *surv;                       // KvqSurvivors: work items that passed the 16-base test, verified behind the kernel (kvq_verify_survivors)
-    uint32_t ntiles, tile_bytes, dbg, pad_, redo_cap, pad2_;
+    uint32_t ntiles, tile_bytes, dbg, pad_, redo_cap;
+    uint32_t surv_cap;                // slots of the survivors' list (read from here, not from the list's header: that line is busy with the slot counter's atomics)
 };
 // Tiles are handed out by counters.  One counter for the whole launch is a ceiling by itself: a word in
 // memory takes about 88 atomic adds per microsecond (MI355X_MICROARCH.md, "dequeue"), i.e. 3.5 TB/s of
@@ -981,7 +982,7 @@ __device__ __forceinline__ bool seed_live_text(GlbBytes read, GlbBytes seq, int 
     } else diff &= (1u << (8 * K)) - 1u;
     return diff == 0u;
 }
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(1024)
 kvq_verify_survivors(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, const void *surv_, const unsigned int *__restrict__ fail,
                      int K, int stride, int pitch)
 {
@@ -990,8 +991,15 @@ kvq_verify_survivors(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos
     const uint32_t n = Sv.count[0] < Sv.count[1] ? Sv.count[0] : Sv.count[1];      // (slots handed out, the list's size)
     const int me = P.maxerrors, mo = P.minoverlap;
     const uint32_t step = gridDim.x * blockDim.x;
-    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += step) {
-        const uint32_t i = base + (threadIdx.x & 63u);
+    // The hits of a round take their arena slots together: the waves add their counts up in LDS, ONE add on the arena's counter for the
+    // workgroup and round (300 of them on the headline input).  Two adds per wave and round -- kvq_emit's way -- were 9 400 on a word
+    // that takes some 88 a microsecond: the kernel's whole 108 us.
+    __shared__ uint32_t n_round, arena_at;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += step) {          // (the same rounds for every wave of the workgroup)
+        if (threadIdx.x == 0) n_round = 0;
+        __syncthreads();
+        const uint32_t i = base + threadIdx.x;
         bool hitAB = false, hitC = false;
         int s = 0, rl = 0, lenAB = 0, lenC = 0, sposAB = 0, sposC = 0; uint32_t keyAB = 0, keyC = 0; int64_t fpos = 0;
         if (i < n) {
@@ -1037,22 +1045,67 @@ kvq_verify_survivors(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos
                         }
                 }
                 if (!earlier) {
+                    // the whole overlap, 64 bytes a step (eight loads in flight: this kernel has the registers), then 16 at a time, and what is
+                    // left behind the last whole 16 as ONE more load that reaches back over bytes already counted (they are masked off)
                     int mism = 0, j = 0;
                     const GlbBytes x = read + a, y = seq + (a + d);
-                    for (; j + 16 <= L && mism <= me; j += 16) {
-                        typedef u32x4_t __attribute__((aligned(1))) u32x4_any;
-                        const u32x4_t xv = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_any *>(x + j);
-                        const u32x4_t yv = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_any *>(y + j);
-                        mism += diff_bytes(xv.x, yv.x) + diff_bytes(xv.y, yv.y) + diff_bytes(xv.z, yv.z) + diff_bytes(xv.w, yv.w);
+                    typedef u32x4_t __attribute__((aligned(1))) u32x4_any;
+                    typedef const __attribute__((address_space(1))) u32x4_any *GlbVec;
+                    auto diff16 = [](const u32x4_t xv, const u32x4_t yv) { return diff_bytes(xv.x, yv.x) + diff_bytes(xv.y, yv.y) + diff_bytes(xv.z, yv.z) + diff_bytes(xv.w, yv.w); };
+                    for (; j + 64 <= L && mism <= me; j += 64) {
+                        u32x4_t xv[4], yv[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) { xv[t] = *(GlbVec)(x + j + 16 * t); yv[t] = *(GlbVec)(y + j + 16 * t); }
+#pragma unroll
+                        for (int t = 0; t < 4; t++) mism += diff16(xv[t], yv[t]);
                     }
-                    for (; j + 4 <= L && mism <= me; j += 4) mism += diff_bytes(glb_u32(x + j), glb_u32(y + j));
-                    for (; j < L && mism <= me; j++) mism += (x[j] != y[j]);
+                    for (; j + 16 <= L && mism <= me; j += 16) mism += diff16(*(GlbVec)(x + j), *(GlbVec)(y + j));
+                    if (j < L && mism <= me) {
+                        if (L >= 16) {
+                            const u32x4_t xv = *(GlbVec)(x + L - 16), yv = *(GlbVec)(y + L - 16);
+                            const int keep = L - j;                                   // the last `keep` (1..15) bytes of the vector are new
+                            uint32_t dx[4] = { xv.x ^ yv.x, xv.y ^ yv.y, xv.z ^ yv.z, xv.w ^ yv.w };
+#pragma unroll
+                            for (int t = 0; t < 4; t++) {
+                                const int first_new = 16 - keep - 4 * t;              // bytes of dword t in front of this index are old
+                                const uint32_t m = first_new <= 0 ? 0xFFFFFFFFu : first_new >= 4 ? 0u : 0xFFFFFFFFu << (8 * first_new);
+                                mism += diff_bytes(dx[t] & m, 0u);
+                            }
+                        } else {
+                            for (; j + 4 <= L && mism <= me; j += 4) mism += diff_bytes(glb_u32(x + j), glb_u32(y + j));
+                            for (; j < L && mism <= me; j++) mism += (x[j] != y[j]);
+                        }
+                    }
                     if (mism <= me) { hitAB = canAB; hitC = canC; }
                 }
             }
         }
-        kvq_emit(P, hitAB, fpos, s, sposAB, lenAB, rl, keyAB);
-        kvq_emit(P, hitC, fpos, s, sposC, lenC, rl, keyC);
+        const uint64_t mAB = __ballot(hitAB), mC = __ballot(hitC);
+        const uint32_t nAB = (uint32_t)__popcll(mAB), nC = (uint32_t)__popcll(mC);
+        uint32_t at = 0;
+        if (nAB + nC) {
+            if (lane == 0u) at = atomicAdd(&n_round, nAB + nC);
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        }
+        __syncthreads();
+        const uint32_t total = n_round;
+        if (total) {                                               // (uniform over the workgroup)
+            if (threadIdx.x == 0) arena_at = atomicAdd(P.arena_n, total);      // (counts on beyond the arena's end, as kvq_emit does: the host sees the overflow there)
+            __syncthreads();
+            const uint32_t o = arena_at + at;
+            KvqHit h;
+            h.fpos = fpos; h.seq_nr = s; h.readlength = rl; h.blob_off = 0;
+            if (hitAB) {
+                const uint32_t idx = o + (uint32_t)__popcll(mAB & kvq_lanemask_lt());
+                h.seq_pos = sposAB; h.length = lenAB; h.key = keyAB;
+                if (idx < P.arena_cap) P.arena[idx] = h;
+            }
+            if (hitC) {
+                const uint32_t idx = o + nAB + (uint32_t)__popcll(mC & kvq_lanemask_lt());
+                h.seq_pos = sposC; h.length = lenC; h.key = keyC;
+                if (idx < P.arena_cap) P.arena[idx] = h;
+            }
+        }
     }
 }
 

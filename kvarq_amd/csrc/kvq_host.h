@@ -113,6 +113,7 @@ struct kvq_scan {
     // per-batch scratch
     uint32_t cus = 0;                  // compute units of the scan's device (asked once)
     bool seen_skips = false;           // a tile of this scan object has left records to the redo before (kept across resets: sizes the redo's launches)
+    uint32_t surv_cap = 0;             // slots of d_surv's list (KVQ_SURV_CAP, or what the environment cut it to)
     DevBuf d_surv;                     // what passed the scan kernel's 16-base test, for kvq_verify_survivors (KvqSurvivors)
     DevBuf d_redo;                     // the redo of skipped tiles (KvqRedo: count, newline quadruples, record starts, trimmed reads)
     DevBuf d_skipped, d_chunk_off, d_seg_base, d_seg_cnt, d_chunk_nrec, d_rec_base, d_nl4, d_rec_start, d_read_off, d_read_len;

@@ -81,7 +81,7 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         a.ntiles = (uint32_t)nt; a.tile_bytes = TILE; a.dbg = dbg; a.pad_ = stagger;
         a.redo = s->d_redo.p; a.redo_cap = KVQ_REDO_CAP - KVQ_LONG_CAP; a.fail = s->cur_fail;
         static const bool surv_off = getenv("KVQ_SURVIVORS") && getenv("KVQ_SURVIVORS")[0] == '0';      // (tests: 0 = every work item is verified where it is found)
-        a.surv = surv_off ? nullptr : s->d_surv.p;
+        a.surv = surv_off ? nullptr : s->d_surv.p; a.surv_cap = s->surv_cap;
         memcpy(s->pool.h + first_at + first_b, &a, sizeof(a));
     }
     {
@@ -144,11 +144,11 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         hipLaunchKernelGGL(kern, dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
     }
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
-    { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }
     // what passed the scan kernel's 16-base test (0.02 work items per read of the bench workload), byte-exact: a lane each, fixed grid, count on the device
     if (s->d_surv.p)
-        hipLaunchKernelGGL(kvq_verify_survivors, dim3(256), dim3(256), 0, s->stream, P, d_data, fpos_base, (const void *)s->d_surv.p, (const unsigned int *)s->cur_fail,
-                           ix->k, ix->stride, ix->pitch);              // (kvq_validate_tiles and what follows run beside the next scan)
+        hipLaunchKernelGGL(kvq_verify_survivors, dim3(256), dim3(1024), 0, s->stream, P, d_data, fpos_base, (const void *)s->d_surv.p, (const unsigned int *)s->cur_fail,
+                           ix->k, ix->stride, ix->pitch);
+    { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }              // (kvq_validate_tiles and what follows run beside the next scan)
     if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                        d_first, d_report, s->cur_fail, reinterpret_cast<KvqSkippedTile *>(s->pool.d + skip_at), d_chunk_off, TILE);

@@ -385,6 +385,7 @@ extern "C" kvq_scan *kvq_scan_create(const kvq_table *t, void *d_counters)
         unsigned int hdr[64] = { 0 };
         hdr[1] = KVQ_SURV_CAP;
         if (const char *e = getenv("KVQ_SURV_CAP")) { const long v = atol(e); if (v >= 0 && v < (long)KVQ_SURV_CAP) hdr[1] = (unsigned int)v; }
+        s->surv_cap = hdr[1];
         if (hipMemcpyAsync(s->d_surv.p, hdr, 256, hipMemcpyHostToDevice, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) { kvq_scan_destroy(s); return nullptr; }
     }
     if (s->d_redo.ensure(KvqRedo::bytes()) != KVQ_OK) { kvq_scan_destroy(s); return nullptr; }

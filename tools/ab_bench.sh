@@ -9,7 +9,7 @@ for round in 1 2 3; do
     cp $f kvarq_amd/libkvarq_hip.so
     python3 bench.py --no-cpu-baseline --steps 20 "$@" > /tmp/ab.json 2> /tmp/ab.err
     python3 -c "
-import json,sys;d=json.load(open('/tmp/ab.json'));print(sys.argv[1], 'kernel %.4f ms  step %.4f ms  hits %d' % (d['roofline']['avg_launch_ms'], d['ms_per_step'], d['config']['hits_per_step']))" $(basename $f)
+import json,sys;d=json.load(open('/tmp/ab.json'));print(sys.argv[1], 'kernel %.4f ms  step %.4f ms  all-kernels %.4f ms  hits %d' % (d['roofline']['avg_launch_ms'], d['ms_per_step'], d['roofline'].get('all_kernels_ms_per_step') or 0, d['config']['hits_per_step']))" $(basename $f)
   done
 done
 cp /tmp/lib_orig.so kvarq_amd/libkvarq_hip.so
