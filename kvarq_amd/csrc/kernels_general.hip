@@ -572,21 +572,31 @@ kvq_fold_batch(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base,
         const uint8_t *src = data + (fpos - fpos_base) + (seq_pos < 0 ? -seq_pos : 0);
         const uint8_t *seq = P.tab + at;
         uint8_t *dst = P.blob + boff;
-        // four bases a step (unaligned dwords; the buffers have slack behind their ends), all loads of a step in flight together
-        for (uint32_t q = 0; __any(q < ulen); q += 4u) {
-            if (q < ulen) {
-                uint32_t x, y;
-                __builtin_memcpy(&x, src + q, 4); __builtin_memcpy(&y, seq + q, 4);
-                const uint32_t nq = ulen - q < 4u ? ulen - q : 4u;
-                if (nq < 4u) { const uint32_t keep = (1u << (8u * nq)) - 1u; y = (y & keep) | (x & ~keep); }      // (bytes behind the hit: "equal")
-                if (x != y)
-                    for (uint32_t j = 0; j < nq; j++) {
-                        const uint8_t c = (uint8_t)(x >> (8u * j));
-                        if (c != (uint8_t)(y >> (8u * j))) atomicAdd(&P.ctr[P.off_mut + (at + q + j) * 6 + base_class(c)], 1ull);   // analyse.py:77-78
+        // sixteen bases a step (unaligned vectors; the buffers have slack behind their ends), the loads of a step in flight together:
+        // a 150-base hit is ten trips to memory one behind the other (four bases a step were 38 of them, and the kernel's whole time)
+        typedef uint32_t u32x4_any __attribute__((ext_vector_type(4), aligned(1)));
+        for (uint32_t q0 = 0; __any(q0 < ulen); q0 += 16u) {
+            if (q0 < ulen) {
+                const u32x4_any xv = *reinterpret_cast<const u32x4_any *>(src + q0), yv = *reinterpret_cast<const u32x4_any *>(seq + q0);
+                const uint32_t xs[4] = { xv.x, xv.y, xv.z, xv.w }, ys[4] = { yv.x, yv.y, yv.z, yv.w };
+                const uint32_t left = ulen - q0;                                       // bases of the hit from q0 on
+#pragma unroll
+                for (uint32_t t = 0; t < 4u; t++) {
+                    const uint32_t q = q0 + 4u * t;
+                    if (4u * t < left) {
+                        const uint32_t x = xs[t]; uint32_t y = ys[t];
+                        const uint32_t nq = left - 4u * t < 4u ? left - 4u * t : 4u;
+                        if (nq < 4u) { const uint32_t keep = (1u << (8u * nq)) - 1u; y = (y & keep) | (x & ~keep); }      // (bytes behind the hit: "equal")
+                        if (x != y)
+                            for (uint32_t j = 0; j < nq; j++) {
+                                const uint8_t c = (uint8_t)(x >> (8u * j));
+                                if (c != (uint8_t)(y >> (8u * j))) atomicAdd(&P.ctr[P.off_mut + (at + q + j) * 6 + base_class(c)], 1ull);   // analyse.py:77-78
+                            }
                     }
+                }
                 if (fits) {                                                           // 437
-                    if (nq == 4u) __builtin_memcpy(dst + q, &x, 4);
-                    else for (uint32_t j = 0; j < nq; j++) dst[q + j] = (uint8_t)(x >> (8u * j));
+                    if (left >= 16u) *reinterpret_cast<u32x4_any *>(dst + q0) = xv;
+                    else for (uint32_t j = 0; j < left; j++) dst[q0 + j] = (uint8_t)(xs[j >> 2] >> (8u * (j & 3u)));
                 }
             }
         }
