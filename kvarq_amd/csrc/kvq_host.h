@@ -143,7 +143,7 @@ struct kvq_scan {
     std::vector<Batch> batches;
     bool host_batches = false;
     int64_t host_pending = -1;           // index of the host batch in flight (kvq_scan_host_async), -1: none
-    hipEvent_t ev_chain = nullptr;       // this scan's last seed-filter launch is through (recorded right behind the scan kernel, in front of kvq_validate_tiles: what the next scan of the process waits for)
+    hipEvent_t ev_chain = nullptr;       // this scan's last seed-filter launch and its kvq_verify_survivors are through (recorded behind the two, in front of kvq_validate_tiles: what the next scan of the process waits for)
     int64_t records = 0;
     int64_t parsed = 0, total = 0;
     // timing

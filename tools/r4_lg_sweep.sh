@@ -1,0 +1,7 @@
+cd ${GRAFT_REPO_ROOT:-.}
+for lg in 2 1 3 -1 2 1; do
+  export KVQ_LG=$lg
+  python3 bench.py --no-cpu-baseline --no-end-to-end --steps 20 > /tmp/lg.json 2>/tmp/lg.err
+  python3 -c "
+import json,sys;d=json.load(open('/tmp/lg.json'));print('KVQ_LG', sys.argv[1], 'kernel %.4f ms  step %.4f ms  hits %d' % (d['roofline']['avg_launch_ms'], d['ms_per_step'], d['config']['hits_per_step']))" $lg
+done
