@@ -968,19 +968,14 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
 // canonical discoverer among the seeds that find the diagonal, the emit); the read's bases come from the batch's text in global
 // memory instead of the tile's planes, which are gone by now: a seed is live when the K codes (byte >> 1) & 3 of the read equal the
 // sequence's -- the very codes the planes held.
-__device__ __forceinline__ bool seed_live_text(GlbBytes read, GlbBytes seq, int K, int rl, int rp, int seql, int sq)
+// do the K bases at x and at y have equal codes?  (bounds are the caller's.)  K <= 8 bases as two (unaligned) 4-byte words a side; bytes
+// behind the K-th are masked off (they exist: a newline follows the read, the table has 64 bytes of slack)
+__device__ __forceinline__ bool seed_same_text(GlbBytes x, GlbBytes y, int K)
 {
-    if (rp < 0 || rp + K > rl || sq < 0 || sq + K > seql) return false;
-    // K <= 8 bases as two (unaligned) 4-byte words a side; bytes behind the K-th are masked off (they exist: a newline follows the read,
-    // the table has 64 bytes of slack)
-    const uint32_t x0 = glb_u32(read + rp), y0 = glb_u32(seq + sq);
-    uint32_t diff = (x0 ^ y0) & 0x06060606u;
-    if (K > 4) {
-        const uint32_t x1 = glb_u32(read + rp + 4), y1 = glb_u32(seq + sq + 4);
-        const uint32_t m1 = K >= 8 ? 0x06060606u : (0x06060606u & ((1u << (8 * (K - 4))) - 1u));
-        diff |= (x1 ^ y1) & m1;
-    } else diff &= (1u << (8 * K)) - 1u;
-    return diff == 0u;
+    const uint32_t x0 = glb_u32(x), y0 = glb_u32(y), x1 = glb_u32(x + 4), y1 = glb_u32(y + 4);
+    const uint32_t m0 = K >= 4 ? 0x06060606u : (0x06060606u & ((1u << (8 * K)) - 1u));
+    const uint32_t m1 = K >= 8 ? 0x06060606u : K > 4 ? (0x06060606u & ((1u << (8 * (K - 4))) - 1u)) : 0u;
+    return (((x0 ^ y0) & m0) | ((x1 ^ y1) & m1)) == 0u;
 }
 extern "C" __global__ void __launch_bounds__(1024)
 kvq_verify_survivors(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, const void *surv_, const unsigned int *__restrict__ fail,
@@ -1031,33 +1026,51 @@ kvq_verify_survivors(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos
                 // canonical discoverer FIRST: no live seed earlier in the order [ALL-index read blocks by position] then [ANCHOR blocks by
                 // number].  A true hit's diagonal is met by half a dozen seeds, so five survivors in six end here, after a load or two,
                 // and only the one that will emit compares the whole overlap (the in-place form counts first: it has the bytes at hand).
+                // (every seed of the order is looked at, with no exit in between: the loads of all of them are in flight together -- the one
+                // survivor in six that IS the first discoverer went through nine dependent trips to memory otherwise, and its wave with it.
+                // A seed that does not exist reads offset 0 of the read and of the sequence and is then left out of the answer.)
                 bool earlier = false;
-                for (int jj = 0; jj <= me && !earlier; jj++) {
-                    const int ph = jj * K, pt = rl - (jj + 1) * K;
-                    if (ph + K <= rl && (kind == 0u || ph < p)) earlier = seed_live_text(read, seq, K, rl, ph, seql, ph + d);
-                    if (!earlier && pt >= 0 && (kind == 0u || pt < p)) earlier = seed_live_text(read, seq, K, rl, pt, seql, pt + d);
+                auto live = [&](bool want, int rp, int sq) -> bool {
+                    const bool ok = want && rp >= 0 && rp + K <= rl && sq >= 0 && sq + K <= seql;
+                    return seed_same_text(read + (ok ? rp : 0), seq + (ok ? sq : 0), K) && ok;
+                };
+                const int sft = d & (stride - 1);                         // the one anchor offset whose read position is a probed one ((o - d) % stride == 0)
+                constexpr int JJ = 4;
+#pragma unroll
+                for (int jj = 0; jj < JJ; jj++) {
+                    const int ph = jj * K, pt = rl - (jj + 1) * K, o = jj * pitch + sft;
+                    const bool in = jj <= me;
+                    const bool e0 = live(in && (kind == 0u || ph < p), ph, ph + d);
+                    const bool e1 = live(in && (kind == 0u || pt < p), pt, pt + d);
+                    const bool e2 = live(in && kind == 0u && o < q, o - d, o);
+                    earlier = earlier || e0 || e1 || e2;
                 }
-                if (kind == 0u) {
-                    for (int jj = 0; jj <= me && !earlier; jj++)
-                        for (int sft = 0; sft < stride && !earlier; sft++) {
-                            const int o = jj * pitch + sft;
-                            if (o < q && ((o - d) & (stride - 1)) == 0) earlier = seed_live_text(read, seq, K, rl, o - d, seql, o);
-                        }
+                for (int jj = JJ; jj <= me && !earlier; jj++) {           // (more than three errors allowed: the rest of the order, one seed at a time)
+                    const int ph = jj * K, pt = rl - (jj + 1) * K, o = jj * pitch + sft;
+                    earlier = live(kind == 0u || ph < p, ph, ph + d) || live(kind == 0u || pt < p, pt, pt + d) || live(kind == 0u && o < q, o - d, o);
                 }
                 if (!earlier) {
-                    // the whole overlap, 64 bytes a step (eight loads in flight: this kernel has the registers), then 16 at a time, and what is
+                    // the whole overlap, 128 bytes a step (sixteen loads in flight: this kernel has the registers), then 64, then 16 at a time, and what is
                     // left behind the last whole 16 as ONE more load that reaches back over bytes already counted (they are masked off)
                     int mism = 0, j = 0;
                     const GlbBytes x = read + a, y = seq + (a + d);
                     typedef u32x4_t __attribute__((aligned(1))) u32x4_any;
                     typedef const __attribute__((address_space(1))) u32x4_any *GlbVec;
                     auto diff16 = [](const u32x4_t xv, const u32x4_t yv) { return diff_bytes(xv.x, yv.x) + diff_bytes(xv.y, yv.y) + diff_bytes(xv.z, yv.z) + diff_bytes(xv.w, yv.w); };
-                    for (; j + 64 <= L && mism <= me; j += 64) {
+                    for (; j + 128 <= L && mism <= me; j += 128) {
+                        u32x4_t xv[8], yv[8];
+#pragma unroll
+                        for (int t = 0; t < 8; t++) { xv[t] = *(GlbVec)(x + j + 16 * t); yv[t] = *(GlbVec)(y + j + 16 * t); }
+#pragma unroll
+                        for (int t = 0; t < 8; t++) mism += diff16(xv[t], yv[t]);
+                    }
+                    if (j + 64 <= L && mism <= me) {
                         u32x4_t xv[4], yv[4];
 #pragma unroll
                         for (int t = 0; t < 4; t++) { xv[t] = *(GlbVec)(x + j + 16 * t); yv[t] = *(GlbVec)(y + j + 16 * t); }
 #pragma unroll
                         for (int t = 0; t < 4; t++) mism += diff16(xv[t], yv[t]);
+                        j += 64;
                     }
                     for (; j + 16 <= L && mism <= me; j += 16) mism += diff16(*(GlbVec)(x + j), *(GlbVec)(y + j));
                     if (j < L && mism <= me) {

@@ -162,6 +162,7 @@ extern "C" __global__ void __launch_bounds__(256)
 kvq_collect_skipped(const uint8_t *__restrict__ data, const KvqSkippedTile *__restrict__ tiles, uint32_t ntiles_, KvqDevCount dc,
                     uint32_t *__restrict__ nl4, uint32_t *__restrict__ rec_start, unsigned int *__restrict__ rec_count, uint32_t rec_cap)
 {
+    KVQ_BESIDE_SCAN();
     const uint32_t ntiles = kvq_dev_count(ntiles_, dc);
     const int lane = kvq_lane();
     for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < ntiles; w += gridDim.x * 4u) {
@@ -259,6 +260,7 @@ kvq_trim_records(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_bas
                  uint32_t *__restrict__ read_off, int32_t *__restrict__ read_len, int32_t count, uint32_t rpw,
                  unsigned int *__restrict__ long_count, uint32_t long_top)
 {
+    KVQ_BESIDE_SCAN();
     // long_count (the redo of skipped tiles only): a read of KVQ_LONG_READ bases or more goes to a list of its own, filled
     // from read_off[long_top] / read_len[long_top] downwards, at most KVQ_LONG_CAP of them: the matcher is launched once for
     // the many ordinary reads (a wave a read) and once for the few long ones (a read's sequences and alignments spread
@@ -404,6 +406,7 @@ kvq_match_all(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base, 
               const uint32_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
               const int32_t *__restrict__ seq_list, int32_t nlist)
 {
+    KVQ_BESIDE_SCAN();
     const int lane = kvq_lane();
     const uint32_t nrec = kvq_dev_count(nrec_, dc);
     for (uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6); g < nrec; g += gridDim.x * 4u) {
@@ -461,6 +464,7 @@ kvq_match_long(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base,
                const uint32_t *__restrict__ read_off, const int32_t *__restrict__ read_len,
                const int32_t *__restrict__ seq_list, int32_t nlist, uint32_t long_top)
 {
+    KVQ_BESIDE_SCAN();
     // work units (read, group of four sequences -- a wave each --, share of the alignments), dealt out over the grid in
     // turn: a launch of fixed size serves one long read as evenly as a thousand
     __shared__ uint32_t R[KVQ_LONG_LDS / 4u + 2u];
@@ -539,6 +543,7 @@ extern "C" __global__ void __launch_bounds__(256)
 kvq_fold_batch(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base,
                const unsigned int *__restrict__ range_begin, const unsigned int *__restrict__ range_end)
 {
+    KVQ_BESIDE_SCAN();
     const uint32_t h0 = *range_begin;
     uint32_t h1 = *range_end; if (h1 > P.arena_cap) h1 = P.arena_cap;
     const int lane = kvq_lane();
@@ -608,6 +613,7 @@ kvq_fold_batch(KvqParams P, const uint8_t *__restrict__ data, int64_t fpos_base,
 extern "C" __global__ void __launch_bounds__(256)
 kvq_cov_apply(KvqParams P)
 {
+    KVQ_BESIDE_SCAN();
     const int s = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (s >= P.nseq) return;
     const int lane = kvq_lane();

@@ -69,6 +69,7 @@ kvq_finish_plan(const unsigned int *__restrict__ arena_n, uint32_t arena_cap, co
                 unsigned long long blob_cap, const unsigned long long *__restrict__ err, long long lo, long long hi,
                 uint32_t nb_max, KvqFinishState *__restrict__ st)
 {
+    KVQ_BESIDE_SCAN();
     if (threadIdx.x != 0) return;
     KvqFinishState s;
     s.n_raw = *arena_n; s.n = s.n_raw < arena_cap ? s.n_raw : arena_cap;
@@ -85,6 +86,7 @@ kvq_finish_plan(const unsigned int *__restrict__ arena_n, uint32_t arena_cap, co
 __global__ void __launch_bounds__(256)
 kvq_bucket_count(const KvqHit *__restrict__ arena, const KvqFinishState *__restrict__ st, uint32_t *__restrict__ cnt, uint32_t *__restrict__ share_cnt)
 {
+    KVQ_BESIDE_SCAN();
     const uint32_t n = st->n, shift = st->shift, bc = st->bc; const long long lo = st->lo;
     const int lane = kvq_lane();
     for (uint32_t h0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); h0 < n; h0 += gridDim.x * blockDim.x) {     // (a wave stays together)
@@ -129,6 +131,7 @@ __device__ __forceinline__ unsigned long long kvq_block_excl_scan_256(unsigned l
 __global__ void __launch_bounds__(256)
 kvq_bucket_starts(const KvqFinishState *__restrict__ st, uint32_t *__restrict__ cnt_start, const uint32_t *__restrict__ share_cnt)
 {
+    KVQ_BESIDE_SCAN();
     __shared__ unsigned long long sh[256];
     const uint32_t nb = st->nb, bc = st->bc, k = blockIdx.x, tid = threadIdx.x;
     unsigned long long part = 0, tot;
@@ -150,6 +153,7 @@ __global__ void __launch_bounds__(256)
 kvq_bucket_scatter(const KvqHit *__restrict__ arena, const KvqFinishState *__restrict__ st, const uint32_t *__restrict__ start,
                    uint32_t *__restrict__ fill, uint32_t *__restrict__ idx)
 {
+    KVQ_BESIDE_SCAN();
     const uint32_t n = st->n, shift = st->shift; const long long lo = st->lo;
     for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) {
         const uint32_t b = (uint32_t)((uint64_t)(arena[h].fpos - lo) >> shift);
@@ -167,16 +171,26 @@ __global__ void __launch_bounds__(256)
 kvq_bucket_sort(const KvqHit *__restrict__ arena, KvqFinishState *__restrict__ st, const uint32_t *__restrict__ start, uint32_t *__restrict__ idx,
                 unsigned long long *__restrict__ share_len)
 {
+    KVQ_BESIDE_SCAN();
     const int lane = kvq_lane();
     const uint32_t nb = st->nb, bc = st->bc;
     const uint32_t b_lo = blockIdx.x * bc, b_hi = b_lo + bc < nb ? b_lo + bc : nb;
     unsigned long long bytes = 0;
     for (uint32_t b0 = b_lo; b0 < b_hi; b0 += blockDim.x) {      // (the same trip count for every lane of a wave)
-        const uint32_t b = b0 + threadIdx.x;
+        // (neighbouring buckets go to different waves: a share of some sixty buckets is then the work of four waves, not of the first
+        // one alone -- on input whose reads hit a dozen templates each, the wave takes its crowded buckets one behind the other)
+        const uint32_t b = b0 + ((uint32_t)lane * (blockDim.x >> 6) + (threadIdx.x >> 6));
         uint32_t s0 = 0, m = 0;
         if (b < b_hi) { s0 = start[b]; m = start[b + 1] - s0; }
-        for (uint32_t i = 0; i < m; i++) { const int l = arena[idx[s0 + i]].length; bytes += l > 0 ? (unsigned long long)l : 0ull; }
-        if (m > KVQ_BUCKET_MAX) { st->crowded = 1u; m = 0; }
+        // (the bytes of the bucket's hits are summed up where the hits are fetched anyway -- side by side, not one behind the other: a
+        // loop over the bucket's hits in front of everything was two dependent trips to memory per hit, and on input whose reads hit a
+        // dozen templates each it was the whole time of this kernel, and of the finish)
+        auto len_of = [&](uint32_t hit) -> unsigned long long { const int l = arena[hit].length; return l > 0 ? (unsigned long long)l : 0ull; };
+        if (m > KVQ_BUCKET_MAX) {
+            for (uint32_t i = 0; i < m; i++) bytes += len_of(idx[s0 + i]);
+            st->crowded = 1u; m = 0;
+        }
+        if (m == 1u) bytes += len_of(idx[s0]);
         if (m >= 2u && m <= 8u) {
             // the usual bucket: the sort keys of its hits (file_pos; seq_nr, class | ordinal: 16 of a hit's 32
             // bytes) are fetched side by side and sorted in registers together with the hit numbers
@@ -188,6 +202,7 @@ kvq_bucket_sort(const KvqHit *__restrict__ arena, KvqFinishState *__restrict__ s
                 const KvqHit *h = &arena[ix[i]];
                 k1[i] = (uint32_t)i < m ? h->fpos : 0x7FFFFFFFFFFFFFFFll;                      // (empty slots sort last)
                 k2[i] = (uint32_t)i < m ? ((unsigned long long)(uint32_t)h->seq_nr << 32) | h->key : ~0ull;
+                bytes += (uint32_t)i < m && h->length > 0 ? (unsigned long long)h->length : 0ull;
             }
             // odd-even transposition network over the 8 slots (no dynamic register indexing)
 #pragma unroll
@@ -215,6 +230,7 @@ kvq_bucket_sort(const KvqHit *__restrict__ arena, KvqFinishState *__restrict__ s
                 mine = idx[bs0 + (uint32_t)lane];
                 const KvqHit *h = &arena[mine];
                 a1 = h->fpos; a2 = ((unsigned long long)(uint32_t)h->seq_nr << 32) | h->key;
+                bytes += h->length > 0 ? (unsigned long long)h->length : 0ull;          // (any lane's sum will do: the block's lanes are added up below)
             }
             uint32_t rank = 0;                                       // hits that come before this lane's
             for (uint32_t j = 0; j < bm; j++) {
@@ -234,6 +250,7 @@ kvq_bucket_sort(const KvqHit *__restrict__ arena, KvqFinishState *__restrict__ s
 __global__ void __launch_bounds__(1024)
 kvq_scan_hit_bytes(const KvqHit *__restrict__ arena, const uint32_t *__restrict__ order, const KvqFinishState *__restrict__ st, uint8_t *__restrict__ res)
 {
+    KVQ_BESIDE_SCAN();
     __shared__ unsigned long long part[1024];
     const uint32_t n = st->n, tid = threadIdx.x;
     long long *const off = reinterpret_cast<long long *>(res + st->L.hitseq_off);
@@ -259,6 +276,7 @@ __global__ void __launch_bounds__(256)
 kvq_gather_results(const KvqHit *__restrict__ arena, const uint32_t *__restrict__ order, const KvqFinishState *__restrict__ st,
                    const uint8_t *__restrict__ blob_in, unsigned long long blob_cap, uint8_t *__restrict__ res)
 {
+    KVQ_BESIDE_SCAN();
     const int lane = kvq_lane();
     const uint32_t n = st->n;
     const KvqResultLayout L = st->L;
@@ -291,6 +309,7 @@ kvq_gather_shares(const KvqHit *__restrict__ arena, const uint32_t *__restrict__
                   const unsigned long long *__restrict__ share_len, const KvqFinishState *__restrict__ st,
                   const uint8_t *__restrict__ blob_in, unsigned long long blob_cap, uint8_t *__restrict__ res)
 {
+    KVQ_BESIDE_SCAN();
     __shared__ unsigned long long sh[256];
     __shared__ uint32_t c_src[256], c_len[256]; __shared__ unsigned long long c_dst[256];
     const uint32_t nb = st->nb, bc = st->bc, n = st->n, k = blockIdx.x, tid = threadIdx.x;
@@ -337,6 +356,7 @@ __global__ void __launch_bounds__(256)
 kvq_order_clear(const KvqFinishState *__restrict__ st, uint32_t *__restrict__ start, uint32_t *__restrict__ fill,
                 uint32_t *__restrict__ share_cnt, unsigned long long *__restrict__ share_len)
 {
+    KVQ_BESIDE_SCAN();
     const uint32_t words = st->nb + 2u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) { start[i] = 0u; fill[i] = 0u; }
     if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < KVQ_ORDER_BLOCKS; i += blockDim.x) { share_cnt[i] = 0u; share_len[i] = 0ull; }

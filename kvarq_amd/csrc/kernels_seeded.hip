@@ -328,6 +328,7 @@ kvq_validate_tiles(uint32_t nchunks, const uint32_t *__restrict__ tile_first, co
                    unsigned int *__restrict__ spec_fail, KvqSkippedTile *__restrict__ skip_list,
                    const uint32_t *__restrict__ chunk_off, uint32_t tile_bytes)
 {
+    KVQ_BESIDE_SCAN();
     // *spec_fail: bit 0 = the batch failed; from bit 8 on = number of skipped tiles.  What kvq_collect_skipped needs to
     // walk the records such a tile left -- its chunk, what it owns, the newlines of the chunk in front of it, or where the
     // first record it left begins -- goes to skip_list: the redo is enqueued behind this kernel without the host looking
@@ -369,6 +370,7 @@ extern "C" __global__ void __launch_bounds__(256)
 kvq_expand_tiles(uint32_t nchunks, const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ tile_first, uint4 *__restrict__ tile_tab, unsigned int *__restrict__ redo_count,
                  unsigned int *__restrict__ surv_count)
 {
+    KVQ_BESIDE_SCAN();
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && redo_count) { redo_count[0] = 0; redo_count[1] = 0; }      // (records that skipped tiles leave, and the long ones among them, are counted afresh for this launch)
     if (c == 0 && surv_count) surv_count[0] = 0;                             // (and so are the scan kernel's survivors)

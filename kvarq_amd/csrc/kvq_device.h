@@ -127,6 +127,12 @@ __device__ __forceinline__ void kvq_emit(const KvqParams &P, bool hit, int64_t f
 // the redo of what the fused scan leaves (kvq_runtime.hip: run_batch): reads of KVQ_LONG_READ bases or more are matched by a
 // launch of their own, at most KVQ_LONG_CAP of them; a list entry whose record start is KVQ_REDO_TRIMMED has been trimmed
 // (and counted) by the scan kernel already
+// The small kernels of a step (validation, redo, fold, ordering, gather) run BESIDE the next step's persistent scan kernel, in the
+// workgroup slots it leaves free -- on SIMDs whose other six waves are the scan's, at wave priority 1 to 3 in its passes.  At the
+// default priority 0 they only issue when no scan wave can: kvq_bucket_sort took 160 us there against 16 us alone, and the step of a
+// small input was the wait for them.  They are a few microseconds of work: they go first.
+#define KVQ_BESIDE_SCAN() __builtin_amdgcn_s_setprio(3)
+
 #define KVQ_LONG_READ 1024
 #define KVQ_LONG_CAP 2048u
 #define KVQ_REDO_TRIMMED 0xFFFFFFFFu

@@ -277,6 +277,7 @@ extern "C" __global__ void __launch_bounds__(256)
 kvq_commit_batch(unsigned long long *stage, unsigned long long *ctr, unsigned long long *err_stage, unsigned long long *err,
                  const unsigned int *fail, unsigned int *arena_n, unsigned int *range)
 {
+    KVQ_BESIDE_SCAN();
     const bool bad = (*fail & 1u) != 0u;          // (the bits above count skipped tiles: kvq_validate_tiles)
     // (the scan kernel's workgroups add to one of KVQ_STAGE_COPIES copies of the staged counters -- a thousand atomics on
     // one word take 12 us at the end of every launch, an eighth of them a fraction of that: the copies are put together here)
@@ -303,6 +304,7 @@ extern "C" __global__ void __launch_bounds__(256)
 kvq_reset_state(unsigned long long *small, size_t small_words, unsigned long long *ctr, size_t ctr_words,
                 unsigned long long *cov, size_t cov_words)
 {
+    KVQ_BESIDE_SCAN();
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
     for (size_t i = i0; i < small_words; i += step) small[i] = (i == 2 || i == 3) ? ~0ull : 0ull;      // bytes 16..31: err, staged err
     for (size_t i = i0; i < ctr_words; i += step) ctr[i] = 0ull;
@@ -316,6 +318,7 @@ kvq_publish_small(const unsigned int *__restrict__ small, const unsigned int *__
                   const unsigned int *__restrict__ state, unsigned int state_words,
                   unsigned int *host_small, unsigned int *host_fail, unsigned int *host_state)
 {
+    KVQ_BESIDE_SCAN();
     if (threadIdx.x < 8) host_small[threadIdx.x] = small[threadIdx.x];
     for (unsigned int i = threadIdx.x; i < nbatches; i += blockDim.x) host_fail[i] = fail[i];
     for (unsigned int i = threadIdx.x; i < state_words; i += blockDim.x) host_state[i] = state[i];

@@ -1,0 +1,7 @@
+import csv,sys
+rows=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name'].split('(')[0][:28],r.get('Queue_Id','?')) for r in csv.DictReader(open(sys.argv[1]))]
+rows.sort()
+scans=[i for i,r in enumerate(rows) if 'kvq_scan_bp' in r[2]]
+i0=scans[-5]; t0=rows[i0][0]
+for r in rows[i0:scans[-3]+1]:
+    print('%9.1f %8.1f  q%-3s %s' % ((r[0]-t0)/1e3,(r[1]-r[0])/1e3,r[3],r[2]))
