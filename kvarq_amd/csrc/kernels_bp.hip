@@ -292,21 +292,26 @@ __device__ __forceinline__ void bp_runs64(uint64_t m, int n, uint32_t dbg, int &
 {
     const uint64_t nmask = n < 64 ? (1ull << n) - 1ull : ~0ull;
     uint64_t zz = ~m & nmask;                                 // the bad bytes of the slice
-    const int c = __popcll(zz);
+    const int c = __popc((uint32_t)zz) + __popc((uint32_t)(zz >> 32));      // (as 32-bit counts: the comparisons below stay 32-bit ones)
     if (!__any(c > 3) && !(dbg & 4u)) {
         // the usual case, at most three bad bytes in any lane's slice: their positions in closed form
         // (first, second and last one), the runs are the four gaps between them
+        // (v_ffbl / v_ffbh answer -1 for zero by themselves: written as `__ffs(x) - 1` or `__clz` they come with a 64-bit compare and
+        // selects, or an exec-mask branch, around them -- a third of this block's instructions)
         const uint32_t lo = (uint32_t)zz, hi = (uint32_t)(zz >> 32);
+        auto ffbl = [](uint32_t x) -> uint32_t { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; };
+        auto ffbh = [](uint32_t x) -> uint32_t { uint32_t r; asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x)); return r; };
         auto ctz64 = [&](uint32_t l, uint32_t h) -> uint32_t {        // n when there is no bit
-            const uint32_t pl = (uint32_t)(__ffs((int)l) - 1), ph = (uint32_t)(__ffs((int)h) - 1);
-            const uint32_t phi = ph > 0xFFFFFFDFu ? 0xFFFFFFFFu : ph + 32u;
-            uint32_t r = pl < phi ? pl : phi; return r < (uint32_t)n ? r : (uint32_t)n;
+            const uint32_t pl = ffbl(l), ph = ffbl(h) | 32u;
+            const uint32_t r = pl < ph ? pl : ph; return r < (uint32_t)n ? r : (uint32_t)n;
         };
         const uint32_t p1 = ctz64(lo, hi);
         const uint64_t z2 = zz & (zz - 1ull);
         const uint32_t p2 = ctz64((uint32_t)z2, (uint32_t)(z2 >> 32));
-        // one behind the last bad byte (0 when there is none)
-        const uint32_t e = hi ? 64u - (uint32_t)__clz((int)hi) : lo ? 32u - (uint32_t)__clz((int)lo) : 0u;
+        // one behind the last bad byte (0 when there is none): 64 - leading zeros
+        const uint32_t ch = ffbh(hi), cl = ffbh(lo) | 32u;
+        uint32_t lz = ch < cl ? ch : cl; lz = lz < 64u ? lz : 64u;
+        const uint32_t e = 64u - lz;
         const int g0 = (int)p1, g1 = (int)p2 - (int)p1 - 1, g2 = (int)e - (int)p2 - 2, g3 = n - (int)e;
         int bl = g0, bs = 0;
         if (g1 > bl) { bl = g1; bs = (int)p1 + 1; }
@@ -526,6 +531,26 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
             uint32_t n = upto - (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) + incl - cnt;
             if (blk < own_end_l && blk + ST_BLK >= own_end_l) S.n_owned = n + cnt;
             if (__any(cnt != 0u)) {
+                // (the newlines of sequencer records lie 21, 151, 2, 151 bytes apart: no thread has more than two in its 80 bytes.  Then the
+                // first and the second one come in closed form -- lowest set bit of the 80, lowest of what is left -- in two thirds of the
+                // instruction time of two rounds of the general loop below, which picks the first non-empty word with compares and selects)
+                if (n_all <= BP_NLCAP && !__any(cnt > 2u)) {
+                    auto low80 = [](uint32_t w0, uint32_t w1, uint32_t w2) -> uint32_t {     // (an empty word gives 0xFFFFFFFF, with or without the OR)
+                        // (the instruction itself answers -1 for zero; `__ffs(x) - 1` is compiled with a compare and a select around it)
+                        auto ffbl = [](uint32_t x) -> uint32_t { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; };
+                        const uint32_t f0 = ffbl(w0), f1 = ffbl(w1) | 32u, f2 = ffbl(w2) | 64u;
+                        const uint32_t f01 = f0 < f1 ? f0 : f1;
+                        return f01 < f2 ? f01 : f2;
+                    };
+                    const uint32_t p1 = low80(m0, m1, m2);
+                    const uint32_t k0 = m0 & (m0 - 1u), k1 = m0 ? m1 : m1 & (m1 - 1u), k2 = (m0 | m1) ? m2 : m2 & (m2 - 1u);
+                    const uint32_t p2 = low80(k0, k1, k2);
+                    if (cnt) {
+                        S.nl[n] = (uint16_t)(blk + p1);
+                        if (cnt > 1u) S.nl[n + 1u] = (uint16_t)(blk + p2);
+                    }
+                    m0 = m1 = m2 = 0u;
+                }
                 while (__any((m0 | m1 | m2) != 0u)) {
                     const bool in0 = m0 != 0u, in1 = m1 != 0u;
                     const uint32_t w = in0 ? m0 : in1 ? m1 : m2;
