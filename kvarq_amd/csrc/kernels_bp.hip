@@ -762,6 +762,9 @@ kvq_scan_bp(const BpArgs *__restrict__ A_)
             uint32_t sub = (dbg & 128u) ? npass : 0u, step = rpw;             // (diagnostic 128: trim only)
             while (sub < npass) {
                 BTALLY(6, lane == 0);
+                // (a stretch is one turn of this loop unless a queue overflows; what depends on the read only is worked out here, where it is
+                // wanted, not hoisted in front of the loop into a dozen registers and spilled wave masks: the compiler cannot know the trip count)
+                asm volatile("" : "+v"(rl), "+v"(roff));
                 int minrl, me_; const __attribute__((address_space(1))) uint8_t *bmL;
                 {
                     const BpArgsPtr A = bp_args(A_);
