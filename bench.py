@@ -454,8 +454,8 @@ def source_sha256():
     import glob
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, 'kvarq_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'kvarq_amd', 'csrc', '*.h')) +
-                       glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'kvarq_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'kvarq_amd', 'csrc', '*.inc')) +
+                       glob.glob(os.path.join(ROOT, 'kvarq_amd', 'csrc', '*.h')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))):
         h.update(os.path.basename(path).encode())
         with open(path, 'rb') as f:
             h.update(f.read())

@@ -1,3 +1,7 @@
+#!/bin/bash
+# A/B of library builds (kvarq_amd/ab/*.so) on the SMALL inputs -- the sequencer-like 3 M records with and without long reads, 1 M reads --
+# and then on the headline (tools/ab_bench.sh)
+# usage (through gpurun, repo root): bash tools/r4_ab_small.sh
 cd ${GRAFT_REPO_ROOT:-.}
 cp kvarq_amd/libkvarq_hip.so /tmp/lib_orig.so
 for round in 1 2; do

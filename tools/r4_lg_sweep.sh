@@ -1,3 +1,6 @@
+#!/bin/bash
+# the lane group of a read (KVQ_LG: 1 two lanes, 2 four, 3 eight, -1 per tile) on the headline input
+# usage (through gpurun, repo root): bash tools/r4_lg_sweep.sh
 cd ${GRAFT_REPO_ROOT:-.}
 for lg in 2 1 3 -1 2 1; do
   export KVQ_LG=$lg

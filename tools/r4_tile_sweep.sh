@@ -1,3 +1,6 @@
+#!/bin/bash
+# bytes a tile owns (KVQ_TILE) against kernel and step time of the 1 M-read input (configs[1]), one and three steps in flight
+# usage (through gpurun, repo root): bash tools/r4_tile_sweep.sh
 cd ${GRAFT_REPO_ROOT:-.}
 for t in 0 36000 32000 28000 24000 20000 16000; do
   for p in 1 3; do

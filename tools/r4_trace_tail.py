@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The last steps of a rocprofv3 kernel trace, kernel by kernel with its hardware queue: what runs beside which scan
+(usage: python tools/r4_trace_tail.py <..._kernel_trace.csv>)."""
 import csv,sys
 rows=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name'].split('(')[0][:28],r.get('Queue_Id','?')) for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
