@@ -72,6 +72,7 @@ def main():
     ap.add_argument('--maxerrors', type=int, default=2, help='engine setting (product default 2; kvarq/cli.py:410-427 exposes it)')
     ap.add_argument('--minoverlap', type=int, default=25, help='engine setting (product default 25)')
     ap.add_argument('--exhaustive', action='store_true', help='force the exhaustive kernel for every sequence')
+    ap.add_argument('--no-finish-begin', action='store_true', help='(measurement) do not enqueue a job\'s tail ahead of its finish')
     ap.add_argument('--pipeline', type=int, default=0,
                     help='scans in flight: step k+1 is enqueued (on its own scan object and stream) before the results of step k '
                          'are waited for, so the GPU goes from one scan kernel to the next while the host collects a step '
@@ -215,6 +216,8 @@ def main():
         sc.reset()
         for base, nbytes, co in batches:
             sc.scan_device(d_data.ptr + base, nbytes, co, fpos_base=fpos0 + base)
+        if depth > 1 and not args.no_finish_begin:
+            sc.finish_begin()                    # (the job's tail behind its own kernels, not behind the host's wait two jobs later)
         in_flight.append(sc)
 
     def end():

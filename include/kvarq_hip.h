@@ -153,6 +153,12 @@ int32_t kvq_scan_host_drain(kvq_scan *s);
  * record returns KVQ_ERR_FORMAT with the reference's message
  * (workhorse.c:1037-1048) for the first bad record in stream order. */
 int32_t kvq_scan_finish(kvq_scan *s);
+/* optional, for a caller that keeps several scan objects in flight: every batch of this scan has been fed -- enqueue what
+ * kvq_scan_finish would enqueue (the ordering of the hits, the gather, the copies to the host) behind the scan's kernels
+ * now and return at once; kvq_scan_finish later only waits for it.  Without it the host sits out those kernels inside
+ * kvq_scan_finish before it can enqueue its next job (they run beside another job's scan, slowly).  Feeding another batch
+ * afterwards is allowed (kvq_scan_finish enqueues again).  Not part of the reference's interface: engine.findseqs is one call. */
+int32_t kvq_scan_finish_begin(kvq_scan *s);
 
 /* results, valid after kvq_scan_finish until kvq_scan_destroy; arrays are
  * owned by the scan object (engine.Hit fields, workhorse.c:1579-1586) */

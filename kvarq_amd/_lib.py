@@ -52,6 +52,7 @@ PROTOTYPES = {
     'kvq_scan_host_copied': (i32, [vp]),
     'kvq_scan_host_drain': (i32, [vp]),
     'kvq_scan_finish': (i32, [vp]),
+    'kvq_scan_finish_begin': (i32, [vp]),
     'kvq_scan_n_hits': (i64, [vp]),
     'kvq_scan_hit_seq_nr': (P(i32), [vp]),
     'kvq_scan_hit_file_pos': (P(i64), [vp]),

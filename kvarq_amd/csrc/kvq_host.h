@@ -113,6 +113,7 @@ struct kvq_scan {
     // per-batch scratch
     uint32_t cus = 0;                  // compute units of the scan's device (asked once)
     bool seen_skips = false;           // a tile of this scan object has left records to the redo before (kept across resets: sizes the redo's launches)
+    bool tail_pending = false; size_t tail_nb0 = 0, tail_spec = 0;      // the tail of the scan (enqueue_tail) is on the stream for these batches: kvq_scan_finish_begin
     uint32_t surv_cap = 0;             // slots of d_surv's list (KVQ_SURV_CAP, or what the environment cut it to)
     DevBuf d_surv;                     // what passed the scan kernel's 16-base test, for kvq_verify_survivors (KvqSurvivors)
     DevBuf d_redo;                     // the redo of skipped tiles (KvqRedo: count, newline quadruples, record starts, trimmed reads)

@@ -484,6 +484,7 @@ extern "C" int32_t kvq_scan_reset(kvq_scan *s)
     if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
     s->batches.clear(); s->host_batches = false; s->host_pending = -1; s->copied_pending = false; s->records = 0; s->parsed = 0; s->total = 0;
     s->ms_all = s->ms_main = 0; s->main_launches = 0; s->finished = false; s->reduced = false; s->gathered = false; s->path_bits = 0; s->n_hits = 0;
+    s->tail_pending = false;
     s->pool.used = 0;
     const int rr = reset_device_state(s);
     if (g_timing) fprintf(stderr, "reset host %.3f ms\n", now_ms() - tr0);
@@ -801,6 +802,67 @@ extern "C" int32_t kvq_scan_host(kvq_scan *s, const void *h_data, int64_t nbytes
     return rc ? rc : kvq_scan_host_copied(s);
 }
 
+// The tail of a scan -- coverage marks -> counters, the plan of the ordering, the ordering itself, the gather into the result arrays,
+// the words the host needs, the copies -- enqueued behind the scan's kernels: nothing in it needs a number the host would first have
+// to fetch.  finish_once waits for it ONCE; kvq_scan_finish_begin enqueues it ahead of time (a job whose batches are all fed), so that
+// a caller with several jobs in flight finds it done when it comes to kvq_scan_finish -- otherwise the host sits out the ordering
+// kernels of every small job before it enqueues the next one, and those kernels run beside another job's scan at a tenth of their speed.
+static int enqueue_tail(kvq_scan *s)
+{
+    int rc;
+    const kvq_table *t = s->t;
+    const size_t ctr_b = ((size_t)t->ctr_len * 8 + 255) & ~(size_t)255;
+    unsigned char *small = s->pin_small; unsigned int *fail = reinterpret_cast<unsigned int *>(s->pin_small + 64);
+    static const bool no_buckets = getenv("KVQ_ORDER") && !strcmp(getenv("KVQ_ORDER"), "mergesort");
+    uint32_t nb_max = 256; while ((uint64_t)nb_max < 4ull * s->arena_cap && nb_max < KVQ_BUCKETS_MAX) nb_max <<= 1;
+    const size_t order_b = kvq_order_scratch_zero_bytes(nb_max) + (size_t)s->arena_cap * 4;
+    if (order_b > s->d_order.cap || nb_max != s->order_nb_max) {
+        if ((rc = s->d_order.ensure(order_b))) return rc;
+        KVQ_HIP(hipMemsetAsync(s->d_order.p, 0, kvq_order_scratch_zero_bytes(nb_max), s->stream));    // (kvq_order_clear leaves them zero again)
+        s->order_nb_max = nb_max;
+    }
+    const KvqOrderScratch W = kvq_order_scratch(s->d_order.p, nb_max);
+    if ((rc = s->d_finish.ensure(sizeof(KvqFinishState) + 256))) return rc;
+    KvqFinishState *d_st = s->d_finish.as<KvqFinishState>();
+    const size_t res_cap = kvq_result_layout(s->arena_cap, s->blob_cap).total + 256;
+    if ((rc = s->d_result.ensure(res_cap))) return rc;
+    // file positions of this scan lie in [lo, hi)
+    int64_t lo = 0, hi = 1;
+    for (size_t b = 0; b < s->batches.size(); b++) {
+        const int64_t a = s->batches[b].fpos_base, e = a + s->batches[b].nbytes;
+        if (b == 0 || a < lo) lo = a;
+        if (b == 0 || e > hi) hi = e;
+    }
+    const size_t nb0 = s->batches.size();
+    hipLaunchKernelGGL(kvq_finish_plan, dim3(1), dim3(64), 0, s->stream, (const unsigned int *)s->d_arena_n, s->arena_cap,
+                       (const unsigned long long *)s->d_blob_n, (unsigned long long)s->blob_cap, (const unsigned long long *)s->d_err,
+                       (long long)lo, (long long)hi, nb_max, d_st);
+    if (t->nseq > 0)
+        hipLaunchKernelGGL(kvq_cov_apply, dim3((uint32_t)((t->nseq + 3) / 4)), dim3(256), 0, s->stream, make_params(s));
+    if (!no_buckets &&
+        (rc = kvq_order_by_buckets(s->stream, s->d_arena.as<KvqHit>(), s->d_blob.as<uint8_t>(), s->blob_cap, d_st, W, s->d_result.as<uint8_t>()))) return rc;
+    hipLaunchKernelGGL(kvq_publish_small, dim3(1), dim3(256), 0, s->stream, (const unsigned int *)s->d_small.p,
+                       (const unsigned int *)s->d_fail, (unsigned int)nb0, (const unsigned int *)d_st, (unsigned int)(sizeof(KvqFinishState) / 4),
+                       (unsigned int *)small, fail, (unsigned int *)(s->pin_small + 64 + 4 * (size_t)KVQ_MAX_BATCHES));
+    KVQ_HIP(hipGetLastError());
+    // results: as many bytes as the last scan of this handle had (a guess: what is missing is fetched by finish_once)
+    size_t spec = std::min(s->spec_bytes, res_cap);
+    if (ctr_b + spec > s->pin_cap) spec = s->pin_cap > ctr_b ? s->pin_cap - ctr_b : 0;
+    KVQ_HIP(hipMemcpyAsync(s->pin, s->d_ctr, (size_t)t->ctr_len * 8, hipMemcpyDeviceToHost, s->stream));
+    if (spec) KVQ_HIP(hipMemcpyAsync(s->pin + ctr_b, s->d_result.p, spec, hipMemcpyDeviceToHost, s->stream));
+    s->tail_nb0 = nb0; s->tail_spec = spec; s->tail_pending = true;
+    return KVQ_OK;
+}
+
+extern "C" int32_t kvq_scan_finish_begin(kvq_scan *s)
+{
+    kvq_clear_error();
+    if (!s || s->finished) return KVQ_OK;
+    // (a host batch in flight is settled first -- that waits for it; a scan of device batches is not waited for at all)
+    if (s->host_pending >= 0 || s->copied_pending) { const int rc0 = kvq_scan_host_drain(s); if (rc0) return rc0; }
+    return enqueue_tail(s);
+}
+
 static int finish_once(kvq_scan *s)
 {
     const double t0 = now_ms();
@@ -808,50 +870,17 @@ static int finish_once(kvq_scan *s)
     int rc;
     const kvq_table *t = s->t;
     const size_t ctr_b = ((size_t)t->ctr_len * 8 + 255) & ~(size_t)255;
-    unsigned char *small = s->pin_small; unsigned int *fail = reinterpret_cast<unsigned int *>(s->pin_small + 64);
+    unsigned int *fail = reinterpret_cast<unsigned int *>(s->pin_small + 64);
     const KvqFinishState *h_st = reinterpret_cast<const KvqFinishState *>(s->pin_small + 64 + 4 * (size_t)KVQ_MAX_BATCHES);
     static const bool no_buckets = getenv("KVQ_ORDER") && !strcmp(getenv("KVQ_ORDER"), "mergesort");
 
     for (int round = 0; round < 3; round++) {
-        // The whole tail is enqueued behind the scan's kernels -- coverage marks -> counters, the plan of the
-        // ordering, the ordering itself, the gather into the result arrays, the words the host needs, the copies
-        // -- and waited for ONCE: nothing in it needs a number the host would first have to fetch.
-        uint32_t nb_max = 256; while ((uint64_t)nb_max < 4ull * s->arena_cap && nb_max < KVQ_BUCKETS_MAX) nb_max <<= 1;
-        const size_t order_b = kvq_order_scratch_zero_bytes(nb_max) + (size_t)s->arena_cap * 4;
-        if (order_b > s->d_order.cap || nb_max != s->order_nb_max) {
-            if ((rc = s->d_order.ensure(order_b))) return rc;
-            KVQ_HIP(hipMemsetAsync(s->d_order.p, 0, kvq_order_scratch_zero_bytes(nb_max), s->stream));    // (kvq_order_clear leaves them zero again)
-            s->order_nb_max = nb_max;
-        }
-        const KvqOrderScratch W = kvq_order_scratch(s->d_order.p, nb_max);
-        if ((rc = s->d_finish.ensure(sizeof(KvqFinishState) + 256))) return rc;
+        // (the tail may have been enqueued ahead of time, by kvq_scan_finish_begin, for exactly the batches there are)
+        if (!(s->tail_pending && s->tail_nb0 == s->batches.size()) && (rc = enqueue_tail(s))) return rc;
+        s->tail_pending = false;
+        const size_t nb0 = s->tail_nb0;
+        size_t spec = s->tail_spec;
         KvqFinishState *d_st = s->d_finish.as<KvqFinishState>();
-        const size_t res_cap = kvq_result_layout(s->arena_cap, s->blob_cap).total + 256;
-        if ((rc = s->d_result.ensure(res_cap))) return rc;
-        // file positions of this scan lie in [lo, hi)
-        int64_t lo = 0, hi = 1;
-        for (size_t b = 0; b < s->batches.size(); b++) {
-            const int64_t a = s->batches[b].fpos_base, e = a + s->batches[b].nbytes;
-            if (b == 0 || a < lo) lo = a;
-            if (b == 0 || e > hi) hi = e;
-        }
-        const size_t nb0 = s->batches.size();
-        hipLaunchKernelGGL(kvq_finish_plan, dim3(1), dim3(64), 0, s->stream, (const unsigned int *)s->d_arena_n, s->arena_cap,
-                           (const unsigned long long *)s->d_blob_n, (unsigned long long)s->blob_cap, (const unsigned long long *)s->d_err,
-                           (long long)lo, (long long)hi, nb_max, d_st);
-        if (t->nseq > 0)
-            hipLaunchKernelGGL(kvq_cov_apply, dim3((uint32_t)((t->nseq + 3) / 4)), dim3(256), 0, s->stream, make_params(s));
-        if (!no_buckets &&
-            (rc = kvq_order_by_buckets(s->stream, s->d_arena.as<KvqHit>(), s->d_blob.as<uint8_t>(), s->blob_cap, d_st, W, s->d_result.as<uint8_t>()))) return rc;
-        hipLaunchKernelGGL(kvq_publish_small, dim3(1), dim3(256), 0, s->stream, (const unsigned int *)s->d_small.p,
-                           (const unsigned int *)s->d_fail, (unsigned int)nb0, (const unsigned int *)d_st, (unsigned int)(sizeof(KvqFinishState) / 4),
-                           (unsigned int *)small, fail, (unsigned int *)(s->pin_small + 64 + 4 * (size_t)KVQ_MAX_BATCHES));
-        KVQ_HIP(hipGetLastError());
-        // results: as many bytes as the last scan of this handle had (a guess: what is missing is fetched below)
-        size_t spec = std::min(s->spec_bytes, res_cap);
-        if (ctr_b + spec > s->pin_cap) spec = s->pin_cap > ctr_b ? s->pin_cap - ctr_b : 0;
-        KVQ_HIP(hipMemcpyAsync(s->pin, s->d_ctr, (size_t)t->ctr_len * 8, hipMemcpyDeviceToHost, s->stream));
-        if (spec) KVQ_HIP(hipMemcpyAsync(s->pin + ctr_b, s->d_result.p, spec, hipMemcpyDeviceToHost, s->stream));
         KVQ_HIP(hipStreamSynchronize(s->stream));
         const double t1 = now_ms();
 
@@ -945,7 +974,7 @@ int kvq_scan_finish_internal(kvq_scan *s)
         if (s->host_batches) return KVQ_NEED_RESCAN;
         // device batches are still resident: replay them into the larger arena
         std::vector<Batch> again; again.swap(s->batches);
-        drop_events(s); s->main_launches = 0; s->path_bits = 0;
+        drop_events(s); s->main_launches = 0; s->path_bits = 0; s->tail_pending = false;
         if ((rc = reset_device_state(s))) return rc;
         s->pool.used = 0;
         for (size_t b = 0; b < again.size(); b++) {

@@ -139,6 +139,11 @@ class Scanner(object):
                 self._host_batches = None          # too much to keep: an overflow is the caller's to replay
         self._feed_host(arr, co, fpos_base)
 
+    def finish_begin(self):
+        """every batch of this scan has been fed: enqueue the ordering of the hits and the copies to the host now
+        (``kvq_scan_finish_begin``); ``finish`` then only waits.  For callers with several scanners in flight."""
+        _check(_lib.lib().kvq_scan_finish_begin(self.h))
+
     def finish(self, hits=True, stats=True):
         """-> dict with 'hits', 'hitseqs' (bytes), 'stats', 'coverage', 'mutations', 'counters'.
 

@@ -698,6 +698,57 @@ def test_a_full_survivors_list_costs_speed_never_results(cap, monkeypatch):
     s.close(); t.close(); d.free()
 
 
+def test_the_tail_of_a_scan_can_be_enqueued_ahead_of_its_finish():
+    """kvq_scan_finish_begin puts the ordering of the hits and the copies to the host on the stream behind the scan's kernels and returns;
+    kvq_scan_finish then only waits.  Results are those of a plain finish -- also when another batch is fed behind the early tail (finish
+    enqueues the tail again), when it is called twice, on a scan without batches, and with three scanners taking turns as bench.py's do."""
+    g = synth.genome()
+    seqs = synth.both_strands(synth.table(g))
+    host = synth.reads(g, 0, 60000, 150)
+    want = O.scan_memory(host, seqs, fold=True, nthreads=4, **cases.PRODUCT)
+    assert len(want['hits']) > 50
+    co = scan.chunk_offsets(host)
+    half = int(co[len(co) // 2])
+    co_a = co[:len(co) // 2 + 1]; co_b = co[len(co) // 2:] - half
+    t = scan.Table(seqs, **cases.PRODUCT)
+    d = scan.DeviceBuffer(host.nbytes); d.upload(host)
+
+    def same(r):
+        assert tuple(r['hits']) == tuple(want['hits']) and r['hitseqs'] == want['hitseqs']
+        assert r['stats']['nseqhits'] == want['stats']['nseqhits'] and r['stats']['records_parsed'] == want['stats']['records_parsed']
+        assert r['stats']['readlengths'] == want['stats']['readlengths']
+        assert r['coverage'].tolist() == want['coverage'] and r['mutations'].tolist() == want['mutations']
+
+    s = scan.Scanner(t)
+    s.finish_begin()                                                   # (nothing fed yet: harmless)
+    s.scan_device(d.ptr, host.nbytes, co)
+    s.finish_begin(); s.finish_begin()
+    same(s.finish())
+    s.reset()
+    d2 = scan.DeviceBuffer(host.nbytes - half); d2.upload(host[half:])  # (a batch starts on a 16-byte boundary)
+    s.scan_device(d.ptr, half, co_a)
+    s.finish_begin()                                                   # ... and then another batch after all
+    s.scan_device(d2.ptr, host.nbytes - half, co_b, fpos_base=half)
+    same(s.finish())
+    s.reset()
+    s.scan_host(host[:half], fpos_base=0)                              # (host batches: the one in flight is settled first)
+    s.finish_begin()
+    s.scan_host(host[half:], fpos_base=half)
+    s.finish_begin()
+    same(s.finish())
+    ring = [s, scan.Scanner(t), scan.Scanner(t)]
+    flying = []
+    for i in range(7):
+        sc = ring[i % 3]; sc.reset(); sc.scan_device(d.ptr, host.nbytes, co); sc.finish_begin(); flying.append(sc)
+        if len(flying) == 3:
+            same(flying.pop(0).finish())
+    while flying:
+        same(flying.pop(0).finish())
+    for sc in ring:
+        sc.close()
+    t.close(); d.free(); d2.free()
+
+
 def test_one_long_record_costs_its_tile_not_the_batch():
     """300 k ordinary reads with ONE 5 kB record in their middle: the record outgrows the look-ahead of the tile
     that owns it; only that tile's records go through the exhaustive kernels (path: tiles_rescanned, not

@@ -75,7 +75,7 @@ def main():
     def run(k):
         flying = []
         for i in range(k):
-            sc = ring[i % 3]; sc.reset(); sc.scan_device(d.ptr, text.nbytes, co); flying.append(sc)
+            sc = ring[i % 3]; sc.reset(); sc.scan_device(d.ptr, text.nbytes, co); sc.finish_begin(); flying.append(sc)
             if len(flying) == 3:
                 flying.pop(0).finish(hits=False, stats=False)
         while flying:
