@@ -97,7 +97,8 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
 
     // the scan kernel alone between the pair of events its time is read from (bench.py's roofline figure; rocprofv3 --kernel-trace
     // gives the same duration): the table upload, kvq_expand_tiles and kvq_validate_tiles stand outside
-    { const int rcw = kvq_chain_wait(s); if (rcw) return rcw; }                 // behind the last scan kernel of this process (any scan object's)
+    bool pipelined = false;
+    { const int rcw = kvq_chain_wait(s, &pipelined); if (rcw) return rcw; }     // behind the last scan kernel of this process (any scan object's)
     const bool timed = !s->ev_main.empty();
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().first, s->stream));
     typedef void (*BpKernel)(const BpArgs *);
@@ -144,11 +145,19 @@ int kvq_seeded_launch(kvq_scan *s, const KvqParams &P, const uint8_t *d_data, in
         hipLaunchKernelGGL(kern, dim3(grid_seeded), dim3(ST_THREADS), 0, s->stream, d_args);
     }
     if (timed) KVQ_HIP(hipEventRecord(s->ev_main.back().second, s->stream));
-    // what passed the scan kernel's 16-base test (0.02 work items per read of the bench workload), byte-exact: a lane each, fixed grid, count on the device
+    // What passed the scan kernel's 16-base test (0.02 work items per read of the bench workload), byte-exact: a lane each, count on the device.
+    // One job at a time: 256 workgroups of 1024, and the next scan of the process waits for them (31 us).  Several jobs in flight (the
+    // scan in front of this one was still running when this one was enqueued): the next scan starts right behind this one and the
+    // survivors are verified BESIDE it by 64 small workgroups that fit the slots it leaves free -- 120 us of their own, none of the
+    // step's (step 1.086 -> 1.063 ms; with more or larger workgroups beside the scan the step gets longer, tools/r4_sv_mode.sh).
+    static const int sv_env = getenv("KVQ_SV_MODE") ? atoi(getenv("KVQ_SV_MODE")) : -1;      // (tests: 0 always behind the scan, 1 always beside the next)
+    const bool beside = sv_env >= 0 ? sv_env != 0 : pipelined;
+    if (beside) { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }
+    static const int sv_grid = getenv("KVQ_SV_GRID") ? atoi(getenv("KVQ_SV_GRID")) : 64;      // (experiments: workgroups of the kernel beside a scan)
     if (s->d_surv.p)
-        hipLaunchKernelGGL(kvq_verify_survivors, dim3(256), dim3(1024), 0, s->stream, P, d_data, fpos_base, (const void *)s->d_surv.p, (const unsigned int *)s->cur_fail,
-                           ix->k, ix->stride, ix->pitch);
-    { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }              // (kvq_validate_tiles and what follows run beside the next scan)
+        hipLaunchKernelGGL(kvq_verify_survivors, dim3(beside ? sv_grid : 256), dim3(beside ? 256 : 1024), 0, s->stream, P, d_data, fpos_base, (const void *)s->d_surv.p,
+                           (const unsigned int *)s->cur_fail, ix->k, ix->stride, ix->pitch);
+    if (!beside) { const int rcp = kvq_chain_publish(s); if (rcp) return rcp; }            // (kvq_validate_tiles and what follows run beside the next scan)
     if (!(dbg & 64u))          // (diagnostic 64 scans the wrong text on purpose: nothing to validate)
     hipLaunchKernelGGL(kvq_validate_tiles, dim3((uint32_t)((nchunks + 255) / 256)), dim3(256), 0, s->stream, (uint32_t)nchunks,
                        d_first, d_report, s->cur_fail, reinterpret_cast<KvqSkippedTile *>(s->pool.d + skip_at), d_chunk_off, TILE);

@@ -420,10 +420,16 @@ static std::mutex g_chain_lock;
 static hipEvent_t g_chain_done = nullptr;         // recorded behind the main kernel enqueued last
 static const kvq_scan *g_chain_owner = nullptr;   // (the event is its: forgotten when that scan goes away)
 
-int kvq_chain_wait(kvq_scan *s)
+int kvq_chain_wait(kvq_scan *s, bool *behind_a_running_scan)
 {
     std::lock_guard<std::mutex> l(g_chain_lock);
-    if (g_chain_done && g_chain_owner != s) KVQ_HIP(hipStreamWaitEvent(s->stream, g_chain_done, 0));
+    if (behind_a_running_scan) *behind_a_running_scan = false;
+    if (g_chain_done && g_chain_owner != s) {
+        // (is the scan in front still on the device?  Then the caller keeps several jobs in flight, and the one after this will
+        // be enqueued behind this one in the same way: kvq_seeded_launch lets it start without waiting for this scan's survivors)
+        if (behind_a_running_scan) { *behind_a_running_scan = hipEventQuery(g_chain_done) == hipErrorNotReady; (void)hipGetLastError(); }
+        KVQ_HIP(hipStreamWaitEvent(s->stream, g_chain_done, 0));
+    }
     return KVQ_OK;
 }
 int kvq_chain_publish(kvq_scan *s)
