@@ -1,3 +1,6 @@
+#!/bin/bash
+# workgroups of the survivors' kernel beside a scan (KVQ_SV_GRID) against kernel and step time of the headline
+# usage (through gpurun, repo root): bash tools/r4_sv_grid.sh
 cd ${GRAFT_REPO_ROOT:-.}
 for rep in 1 2; do
 for g in 64 32 16 128; do
