@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/${1:-round3}; mkdir -p $O; cd $R
 : > $O/other_configs.txt
 for p in 1 3; do
 echo "== --pipeline $p (1: one step at a time, as in round 1's table; 3: the bench default)" >> $O/other_configs.txt
-for args in "--reads 1000000" "--reads 40000000" "--readlen 300 --table MTBC+barcodes" "--readlen 100" "--readlen 250 --reads 6000000" "--table-scale 8 --reads 4000000" "--table-scale 32 --reads 1000000"; do
+for args in "--reads 1000000" "--reads 40000000" "--readlen 300 --table MTBC+barcodes" "--readlen 100" "--readlen 250 --reads 6000000" "--table-scale 8 --reads 4000000" "--table-scale 32 --reads 1000000" "--table-scale 32 --reads 4000000"; do
   timeout -k 10 300 python3 bench.py $args --pipeline $p --no-cpu-baseline --no-end-to-end --steps 5 > $O/cfg.json 2> $O/cfg.err || { echo "$args: bench.py failed (see cfg.err)" >> $O/other_configs.txt; continue; }
   python3 - "$args" $O/cfg.json >> $O/other_configs.txt <<'PY'
 import json, sys
