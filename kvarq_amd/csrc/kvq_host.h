@@ -97,6 +97,7 @@ int kvq_live_scans();                 // scan objects alive in this process
 // the persistent scan kernels of a process run one behind the other (two at once only get in each other's way): a launch waits for
 // the event the last one published, on its own stream, right in front of its scan kernel -- its table upload and kvq_expand_tiles do not wait
 int kvq_chain_wait(struct kvq_scan *s, bool *behind_a_running_scan = nullptr);
+bool kvq_chain_busy(const struct kvq_scan *s);     // a scan kernel of another scan object of the process is still on the device
 int kvq_chain_publish(struct kvq_scan *s);
 uint32_t kvq_device_cu_count();       // compute units of the current device
 int kvq_comm_reduce_counters(kvq_comm *c, const unsigned long long *d_in, unsigned long long *d_out, int64_t ctr_len, unsigned long long *d_scratch, hipStream_t stream);

@@ -420,6 +420,15 @@ static std::mutex g_chain_lock;
 static hipEvent_t g_chain_done = nullptr;         // recorded behind the main kernel enqueued last
 static const kvq_scan *g_chain_owner = nullptr;   // (the event is its: forgotten when that scan goes away)
 
+// is a scan kernel of ANOTHER scan object of this process still on the device (enqueued or running)?
+bool kvq_chain_busy(const kvq_scan *s)
+{
+    std::lock_guard<std::mutex> l(g_chain_lock);
+    if (!g_chain_done || g_chain_owner == s) return false;
+    const bool busy = hipEventQuery(g_chain_done) == hipErrorNotReady;
+    (void)hipGetLastError();
+    return busy;
+}
 int kvq_chain_wait(kvq_scan *s, bool *behind_a_running_scan)
 {
     std::lock_guard<std::mutex> l(g_chain_lock);
