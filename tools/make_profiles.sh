@@ -17,8 +17,10 @@ step() { echo "== $1" >> $O/progress.txt; }
 if [[ $PART == *a* ]]; then
 step stats;  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 5 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
 step stats1; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- $B --pipeline 1 --steps 5 --warmup 1 --no-cpu-baseline > $O/stats1.log 2>&1
-step fetch;  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
-step write;  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
+# (the counter passes serialise the launches: each would get every workgroup slot, as a job run alone does; the timed launches of the bench line
+# run with jobs in flight, on 960 workgroups -- KVQ_GRID=960 gives the counted launches the timed ones' grid)
+step fetch;  KVQ_GRID=960 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
+step write;  KVQ_GRID=960 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
 step sq1;    timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq1 -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/sq1.log 2>&1
 step sq2;    timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/sq2 -- $BP --steps 2 --warmup 1 --no-cpu-baseline > $O/sq2.log 2>&1
 cd $R

@@ -36,7 +36,7 @@ def main():
     alg = reads * rb / launches_per_step
     rd = 2.0 * fm * 1024.0; wr = wm * 1024.0
     out = {
-        'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --preheat 0 --steps 2 --warmup 1 --no-cpu-baseline (separate passes; tools/make_profiles.sh)',
+        'command': 'KVQ_GRID=960 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --preheat 0 --steps 2 --warmup 1 --no-cpu-baseline (separate passes; tools/make_profiles.sh; KVQ_GRID=960: the grid of the bench line\'s timed launches, which run with jobs in flight -- the counter passes serialise the launches, and a launch alone takes all 1024 workgroup slots: 1.56 x there, more tiles in flight per L2)',
         'kernel': kernel, 'reads_per_gpu': reads, 'launches_per_step': launches_per_step,
         'source_sha256': bench.source_sha256(), 'git_head': head,
         'note': 'gfx950: FETCH_SIZE counts 1/2 of the bytes of a 16-B-per-lane streaming read (MI355X_MICROARCH.md, HBM section), '
